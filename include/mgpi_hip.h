@@ -1,0 +1,157 @@
+/*
+ * mgpi_hip.h - C ABI of libmgpi_hip.so: the MI355X (gfx950) device path for the dense
+ * Gaussian-process hot path of reedessick/muses-gaussian-process-interpolator ("mgpi").
+ *
+ * The reference is pure Python + numpy and has no FFI of its own; the
+ * entry points below are what a ctypes binding at the reference's three numeric call sites
+ * would bind (INTEGRATION.md shows that binding):
+ *
+ *   (i)   Interpolator._x2cov            mgpi/interpolators.py:208-300  -> mgpi_cov_matrix*
+ *         Kernel.cov (row-paired)        mgpi/kernels.py:89-93,128-131,180-185,287-293 -> mgpi_cov_paired
+ *   (ii)  np.linalg.inv / slogdet        mgpi/interpolators.py:92,179,339,343 -> mgpi_potrf*, mgpi_potrs*
+ *   (iii) the `@` contractions           mgpi/interpolators.py:100,125,189,199 -> mgpi_predict_mean*,
+ *                                                                        mgpi_predict_var*, mgpi_condition_cov*
+ *
+ * Conventions
+ *   - everything is IEEE fp64; matrices are row-major (numpy C order), exactly as the
+ *     reference's ndarrays (interpolators.py:247,294).
+ *   - plain pointers and sizes only; no exceptions cross the ABI.
+ *   - every function returns an int status:  0 ok;  > 0 = 1-based index of the first
+ *     non-positive pivot (matrix not positive definite; the reference's
+ *     `assert s > 0, 'covariance is not positive definite!'`, interpolators.py:340, and
+ *     LinAlgError from inv);  < 0 = MGPI_ERR_* below, text via mgpi_last_error().
+ *   - host buffers are borrowed for the duration of the call.  Device buffers are owned by
+ *     the library and referenced through opaque mgpi_mat handles, so K / L / alpha stay in
+ *     HBM between compress() and predict().
+ *   - a ctx is bound to one GPU and is not re-entrant; distinct ctxs may be used from
+ *     distinct threads.
+ *   - there is NO CPU fallback in this library: without a HIP device mgpi_ctx_create fails.
+ */
+#ifndef MGPI_HIP_H
+#define MGPI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGPI_MAX_D      16   /* max input dimensionality (NDKernel length0..length{D-1}, kernels.py:97-118) */
+#define MGPI_MAX_TERMS   8   /* max summands of a CombinedKernel (kernels.py:191-293) */
+
+/* kernel summand types (a1-a4 of SURVEY.md section 8) */
+#define MGPI_TERM_SE     0   /* SquaredExponentialKernel: sigma^2 exp(-sum_d (dx_d/l_d)^2), NO 1/2 (kernels.py:185) */
+#define MGPI_TERM_WHITE  1   /* WhiteNoiseKernel: sigma^2 [x1 == x2 exactly in every coordinate] (kernels.py:131) */
+
+#define MGPI_ERR_ARG     (-1)  /* bad argument (shape mismatch, D or nterms too large, null pointer) */
+#define MGPI_ERR_HIP     (-2)  /* HIP runtime error (incl. no device) */
+#define MGPI_ERR_ALLOC   (-3)  /* device allocation failed */
+#define MGPI_ERR_STATE   (-4)  /* handle used in the wrong state (e.g. potrs on an unfactored matrix) */
+
+/* one summand of the (flattened) CombinedKernel, built from Kernel.params in summand order */
+typedef struct mgpi_kernel_desc {
+    int32_t type;                 /* MGPI_TERM_* */
+    int32_t reserved;
+    double  sigma;                /* params[0] of SE / WhiteNoise */
+    double  order;                /* Matern order (reserved) */
+    double  length[MGPI_MAX_D];   /* SE: params[1:1+D] */
+} mgpi_kernel_desc;
+
+typedef struct mgpi_ctx mgpi_ctx;   /* one GPU + its streams and workspace */
+typedef struct mgpi_mat mgpi_mat;   /* a device-resident row-major fp64 matrix (rows x cols) */
+
+/* ---- library / context ------------------------------------------------------------- */
+const char* mgpi_last_error(void);                 /* thread-local text of the last failure */
+int  mgpi_device_count(int* count);
+/* nb = outer Cholesky block (multiple of 128; 0 -> default 512, BASELINE.json config 3) */
+int  mgpi_ctx_create(int device_id, int nb, mgpi_ctx** out);
+int  mgpi_ctx_destroy(mgpi_ctx* ctx);
+int  mgpi_ctx_sync(mgpi_ctx* ctx);                 /* wait for all queued device work */
+/* raw hipStream_t of the ctx (as void*), for callers that time with HIP events */
+void* mgpi_ctx_stream(mgpi_ctx* ctx);
+/* event timing on the ctx stream: tic records, toc records+synchronises and returns ms */
+int  mgpi_ctx_tic(mgpi_ctx* ctx);
+int  mgpi_ctx_toc(mgpi_ctx* ctx, double* ms);
+
+/* ---- device matrices --------------------------------------------------------------- */
+/* rows are padded to a multiple of 128.  Matrices with cols <= MGPI_MAX_D (coordinate tables, vectors) keep
+ * their natural row stride (ld == cols); wider ones get ld padded to a multiple of 128.  The pads are zero. */
+int  mgpi_mat_alloc(mgpi_ctx* ctx, int64_t rows, int64_t cols, mgpi_mat** out);
+/* same, but always tile-padded (ld multiple of 128) whatever cols is: the form cov/potrf/trsm/gemm operate on */
+int  mgpi_mat_alloc_wide(mgpi_ctx* ctx, int64_t rows, int64_t cols, mgpi_mat** out);
+int  mgpi_mat_free(mgpi_mat* m);
+int  mgpi_mat_upload(mgpi_mat* m, const double* host, int64_t host_ld);     /* host (rows x cols), row stride host_ld */
+int  mgpi_mat_download(const mgpi_mat* m, double* host, int64_t host_ld);
+int  mgpi_mat_shape(const mgpi_mat* m, int64_t* rows, int64_t* cols, int64_t* ld);
+void* mgpi_mat_devptr(const mgpi_mat* m);                                   /* raw device pointer (double*) */
+/* copy src into dst (same logical shape), e.g. keep K before factoring in place */
+int  mgpi_mat_copy(mgpi_ctx* ctx, const mgpi_mat* src, mgpi_mat* dst);
+/* fill the strict upper triangle from the lower one (square), for downloads of a lower-only build */
+int  mgpi_mat_symmetrize(mgpi_ctx* ctx, mgpi_mat* m);
+
+/* ---- (i) kernel operators ---------------------------------------------------------- */
+/* Kernel.cov: row-paired, x1 and x2 both (p, d) row-major host arrays -> out (p,) host */
+int  mgpi_cov_paired(mgpi_ctx* ctx, const double* x1, const double* x2, int64_t p, int d,
+                     const mgpi_kernel_desc* terms, int nterms, double* out);
+
+/* Interpolator._x2cov on host arrays: out (n1, n2) row-major host.  x2 == NULL means x2 = x1. */
+int  mgpi_cov_matrix(mgpi_ctx* ctx, const double* x1, int64_t n1, const double* x2, int64_t n2, int d,
+                     const mgpi_kernel_desc* terms, int nterms, double* out);
+
+/* device-resident form: X1 (n1 x d), X2 (n2 x d) or NULL (= X1) -> out (n1 x n2), all mgpi_mat.
+ * lower_only != 0 (requires X2 == NULL): only tiles on/below the diagonal are written - the
+ * form potrf consumes; halves the work. */
+int  mgpi_cov_matrix_dev(mgpi_ctx* ctx, const mgpi_mat* X1, const mgpi_mat* X2,
+                         const mgpi_kernel_desc* terms, int nterms, int lower_only, mgpi_mat* out);
+
+/* ---- (ii) factor / solve  (the role of np.linalg.inv + slogdet) ---------------------- */
+/* in-place blocked right-looking Cholesky K = L L^T, lower triangle, row-major; the strict
+ * upper triangle is not referenced.  *logdet = 2 sum log L_ii (may be NULL).
+ * returns 0, or k > 0 if the k-th (1-based) pivot is not positive (matrix content then undefined) */
+int  mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet);
+/* solve L L^T X = B in place, B (n x nrhs) device matrix */
+int  mgpi_potrs_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* B);
+/* host convenience: b (n, nrhs) row-major host in, x out (may alias) */
+int  mgpi_potrs(mgpi_ctx* ctx, const mgpi_mat* L, const double* b, int64_t n, int nrhs, double* x);
+/* triangular half-solves used by predict_var / rvs:  L X = B  (trans=0)  or  L^T X = B (trans=1) */
+int  mgpi_trsm_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* B, int trans);
+
+/* ---- (iii) posterior contractions -------------------------------------------------- */
+/* mean[i] = sum_j k(xs_i, x_j) alpha_j   (interpolators.py:117,125) - K* is never materialised.
+ * Xs (m x d), X (n x d), alpha (n x 1), mean (m x 1) */
+int  mgpi_predict_mean_dev(mgpi_ctx* ctx, const mgpi_mat* Xs, const mgpi_mat* X,
+                           const mgpi_kernel_desc* terms, int nterms,
+                           const mgpi_mat* alpha, mgpi_mat* mean);
+/* var[i] = k(xs_i,xs_i) - || L^-1 k(x, xs_i) ||^2  = diag of interpolators.py:199.
+ * m is processed in slabs of at most m_slab queries (0 -> library default) so the n x m_slab
+ * workspace fits HBM. */
+int  mgpi_predict_var_dev(mgpi_ctx* ctx, const mgpi_mat* Xs, const mgpi_mat* X,
+                          const mgpi_kernel_desc* terms, int nterms,
+                          const mgpi_mat* L, int64_t m_slab, mgpi_mat* var);
+/* full posterior covariance cov = K** - (L^-1 K*^T)^T (L^-1 K*^T)  (m x m), for small m
+ * (interpolators.py:148,157,199) */
+int  mgpi_condition_cov_dev(mgpi_ctx* ctx, const mgpi_mat* Xs, const mgpi_mat* X,
+                            const mgpi_kernel_desc* terms, int nterms,
+                            const mgpi_mat* L, mgpi_mat* cov);
+
+/* ---- building blocks exported for tests / the multi-GPU driver ----------------------- */
+/* C (m x n) -= A (m x k) * B^T   with B (n x k)            (trailing update, interpolators.py:179's role)
+ * lower_only != 0: m == n, only tiles on/below the diagonal are updated (syrk when A == B) */
+int  mgpi_gemm_nt_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* B, mgpi_mat* C, int lower_only);
+/* views: a (rows x cols) window of an existing matrix starting at (r0, c0); shares storage,
+ * r0/c0/rows/cols must be multiples of 64 or reach the padded edge */
+int  mgpi_mat_view(const mgpi_mat* m, int64_t r0, int64_t c0, int64_t rows, int64_t cols, mgpi_mat** out);
+
+/* measured throughput probes used by bench.py's roofline leg (not part of the hot path) */
+int  mgpi_probe_mfma_f64(mgpi_ctx* ctx, int iters, double* tflops);
+int  mgpi_probe_hbm(mgpi_ctx* ctx, int64_t bytes, int iters, double* read_gbs, double* write_gbs);
+
+/* per-kernel accumulated HIP-event time of the last mgpi_potrf_dev when profiling is enabled */
+int  mgpi_ctx_set_profile(mgpi_ctx* ctx, int on);
+/* which: 0 = trailing update (syrk), 1 = panel (potf2+trsm+inner gemm), 2 = total; ms and launches */
+int  mgpi_ctx_get_profile(mgpi_ctx* ctx, int which, double* ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGPI_HIP_H */

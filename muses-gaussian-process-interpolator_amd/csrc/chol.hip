@@ -1,0 +1,492 @@
+// Blocked right-looking Cholesky  K = L L^T  (lower, row-major, in place in HBM) and the triangular solves
+// built on it.  Takes the role of np.linalg.inv / np.linalg.slogdet in the reference
+// (mgpi/interpolators.py:92,179,339,343): alpha = L^-T L^-1 f, logdet = 2 sum log L_ii.
+//
+// Two-level blocking: outer block nb (ctx->nb, default 512) for the trailing update on fp64 MFMA (gemm.hip),
+// inner block 64 for the panel: 64x64 potf2 in LDS, 64-wide row trsm with L_jj in LDS, MFMA gemm for the
+// panel-internal (left-looking) updates.
+#include "mgpi_internal.h"
+#include <math.h>
+#include <vector>
+
+#define IB MGPI_IB
+
+// ---- 64x64 diagonal block: unblocked Cholesky in LDS, one workgroup ------------------------------------
+// reads only the lower triangle; writes L (lower) and zeros the strict upper part of the block.
+// info: first failing pivot (1-based, global index pivot_base + k + 1), written with atomicCAS-min semantics.
+// A pivot fails when it is not above MGPI_PIVOT_TOL * K_kk(original): zero/negative pivots (LAPACK's test) and
+// pivots that are pure rounding noise.  The second part is what makes an exactly singular K - duplicated source
+// rows under the exact-equality white noise, where the reference's inv raises LinAlgError - fail here too
+// instead of returning garbage.
+#define MGPI_PIVOT_TOL 2.2e-14   /* 100 eps */
+__global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int64_t lda, int64_t pivot_base,
+                                                    const double* __restrict__ diag0, int* __restrict__ info) {
+    __shared__ double L[IB][IB + 1];
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    if (tid == 0) bad = 0;
+    for (int idx = tid; idx < IB * IB; idx += 256) {
+        const int i = idx >> 6, j = idx & 63;
+        L[i][j] = (j <= i) ? A[i * lda + j] : 0.0;
+    }
+    __syncthreads();
+    for (int kk = 0; kk < IB; ++kk) {
+        const double d = L[kk][kk];
+        const bool ok = d > MGPI_PIVOT_TOL * fabs(diag0[kk]);   // false for NaN too
+        if (!ok) {
+            if (tid == 0 && bad == 0) bad = kk + 1;
+        }
+        const double s = ok ? sqrt(d) : 1.0;
+        __syncthreads();
+        // scale column kk
+        if (tid < IB) {
+            if (tid == kk) L[kk][kk] = s;
+            else if (tid > kk) L[tid][kk] = L[tid][kk] / s;
+        }
+        __syncthreads();
+        // rank-1 update of the trailing lower triangle: (i, j), kk < j <= i
+        const int rem = IB - 1 - kk;
+        for (int idx = tid; idx < rem * rem; idx += 256) {
+            const int i = kk + 1 + idx / rem, j = kk + 1 + idx % rem;
+            if (j <= i) L[i][j] -= L[i][kk] * L[j][kk];
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < IB * IB; idx += 256) {
+        const int i = idx >> 6, j = idx & 63;
+        A[i * lda + j] = L[i][j];
+    }
+    if (tid == 0 && bad != 0) {
+        const int cand = (int)(pivot_base + bad);
+        int old = atomicCAS(info, 0, cand);
+        while (old != 0 && old > cand) {
+            const int prev = atomicCAS(info, old, cand);
+            if (prev == old) break;
+            old = prev;
+        }
+    }
+}
+
+int mgpi_launch_potf2(mgpi_ctx* ctx, double* A, int64_t lda, int64_t pivot_base, const double* diag0) {
+    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, pivot_base, diag0, ctx->d_info);
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- panel trsm: X L_jj^T = A for a block of rows, 64 columns ---------------------------------------
+// one workgroup = 64 threads = 64 rows; the row lives in registers, L_jj in LDS (broadcast reads).
+// x_k = (a_k - sum_{m<k} x_m L[k][m]) / L[k][k]
+__global__ __launch_bounds__(64) void trsm_rows_kernel(const double* __restrict__ Ljj, int64_t ldl,
+                                                       double* __restrict__ A, int64_t lda) {
+    __shared__ double L[IB][IB];          // L[k][m]: row k read as a broadcast
+    __shared__ double T[IB][IB + 1];      // staging tile for coalesced HBM access
+    const int lane = threadIdx.x;
+    double* blk = A + (int64_t)blockIdx.x * IB * lda;
+    for (int r = 0; r < IB; ++r) {
+        L[r][lane] = Ljj[r * ldl + lane];
+        T[r][lane] = blk[r * lda + lane];
+    }
+    __syncthreads();
+    double x[IB];
+#pragma unroll
+    for (int k = 0; k < IB; ++k) x[k] = T[lane][k];
+#pragma unroll
+    for (int k = 0; k < IB; ++k) {
+        double s = x[k];
+#pragma unroll
+        for (int m = 0; m < k; ++m) s -= x[m] * L[k][m];
+        x[k] = s / L[k][k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < IB; ++k) T[lane][k] = x[k];
+    __syncthreads();
+    for (int r = 0; r < IB; ++r) blk[r * lda + lane] = T[r][lane];
+}
+
+int mgpi_launch_trsm_rows(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double* A, int64_t lda, int64_t rows) {
+    if (rows == 0) return 0;
+    MGPI_REQUIRE(rows % IB == 0, "trsm_rows: rows=%lld not a multiple of %d", (long long)rows, IB);
+    hipLaunchKernelGGL(trsm_rows_kernel, dim3((unsigned)(rows / IB)), dim3(64), 0, ctx->stream, Ljj, ldl, A, lda);
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- multi-rhs 64-row block solve:  B <- L_jj^-1 B  (TRANS = false)  or  L_jj^-T B  (TRANS = true) ----
+// B is (64 x n) row-major; one thread per column of B, L_jj in LDS (broadcast), coalesced across threads.
+template <bool TRANS>
+__global__ __launch_bounds__(256) void trsm_cols_kernel(const double* __restrict__ Ljj, int64_t ldl,
+                                                        double* __restrict__ B, int64_t ldb, int64_t n) {
+    __shared__ double L[IB][IB];
+    for (int idx = threadIdx.x; idx < IB * IB; idx += 256) L[idx >> 6][idx & 63] = Ljj[(idx >> 6) * ldl + (idx & 63)];
+    __syncthreads();
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    double x[IB];
+#pragma unroll
+    for (int k = 0; k < IB; ++k) x[k] = B[k * ldb + c];
+    if (!TRANS) {
+#pragma unroll
+        for (int k = 0; k < IB; ++k) {
+            double s = x[k];
+#pragma unroll
+            for (int m = 0; m < k; ++m) s -= L[k][m] * x[m];
+            x[k] = s / L[k][k];
+        }
+    } else {
+#pragma unroll
+        for (int k = IB - 1; k >= 0; --k) {
+            double s = x[k];
+#pragma unroll
+            for (int m = k + 1; m < IB; ++m) s -= L[m][k] * x[m];
+            x[k] = s / L[k][k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < IB; ++k) B[k * ldb + c] = x[k];
+}
+
+int mgpi_launch_trsm_cols(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double* B, int64_t ldb, int64_t n, int trans) {
+    if (n == 0) return 0;
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (trans) hipLaunchKernelGGL(trsm_cols_kernel<true>, grid, block, 0, ctx->stream, Ljj, ldl, B, ldb, n);
+    else hipLaunchKernelGGL(trsm_cols_kernel<false>, grid, block, 0, ctx->stream, Ljj, ldl, B, ldb, n);
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- small helpers ------------------------------------------------------------------------------------
+// padded diagonal := 1 so the padded matrix stays positive definite (rows n..pn)
+__global__ void pad_identity_kernel(double* A, int64_t lda, int64_t n, int64_t pn) {
+    const int64_t i = n + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < pn) A[i * lda + i] = 1.0;
+}
+
+__global__ void save_diag_kernel(const double* __restrict__ A, int64_t lda, int64_t pn, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < pn) out[i] = A[i * lda + i];
+}
+
+// out[0] = sum_i log(A[i][i]) over i < n (single workgroup, fixed summation order => deterministic)
+__global__ __launch_bounds__(256) void logdiag_kernel(const double* __restrict__ A, int64_t lda, int64_t n,
+                                                      double* __restrict__ out) {
+    __shared__ double part[256];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += log(A[i * lda + i]);
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0];
+}
+
+// ---- the factorisation ----------------------------------------------------------------------------------
+extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
+    MGPI_REQUIRE(ctx && K, "mgpi_potrf_dev: null pointer");
+    MGPI_REQUIRE(K->rows == K->cols, "mgpi_potrf_dev: matrix is %lld x %lld, not square", (long long)K->rows, (long long)K->cols);
+    MGPI_REQUIRE(K->pcols >= K->prows || K->pcols >= mgpi_roundup(K->rows, IB),
+                 "mgpi_potrf_dev: matrix must be tile padded (allocate with cols > %d)", MGPI_MAX_D);
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    const int64_t n = K->rows;
+    const int64_t pn = K->prows <= K->pcols ? K->prows : mgpi_roundup(n, IB);   // factored extent (multiple of 64)
+    const int64_t lda = K->ld;
+    double* A = K->d;
+    const int64_t nb = ctx->nb;
+
+    MGPI_HIP_TRY(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
+    if (pn > n) {
+        hipLaunchKernelGGL(pad_identity_kernel, dim3((unsigned)((pn - n + 63) / 64)), dim3(64), 0, ctx->stream, A, lda, n, pn);
+        MGPI_HIP_TRY(hipGetLastError());
+    }
+    if (ctx->diag_len < pn) {
+        if (ctx->d_diag) {
+            MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            MGPI_HIP_TRY(hipFree(ctx->d_diag));
+            ctx->d_diag = nullptr;
+            ctx->diag_len = 0;
+        }
+        MGPI_HIP_TRY(hipMalloc((void**)&ctx->d_diag, (size_t)pn * sizeof(double)));
+        ctx->diag_len = pn;
+    }
+    hipLaunchKernelGGL(save_diag_kernel, dim3((unsigned)((pn + 255) / 256)), dim3(256), 0, ctx->stream, A, lda, pn,
+                       ctx->d_diag);
+    MGPI_HIP_TRY(hipGetLastError());
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (ctx->profile) {
+        MGPI_HIP_TRY(hipEventCreate(&t0));
+        MGPI_HIP_TRY(hipEventCreate(&t1));
+        MGPI_HIP_TRY(hipEventRecord(t0, ctx->stream));
+    }
+
+    for (int64_t r0 = 0; r0 < pn; r0 += nb) {
+        const int64_t w = (pn - r0 < nb) ? (pn - r0) : nb;   // panel width
+        // ---- panel: columns [r0, r0+w), rows [r0, pn); left-looking over 64-wide inner blocks
+        mgpi_prof_begin(ctx);
+        for (int64_t c0 = r0; c0 < r0 + w; c0 += IB) {
+            const int64_t kk = c0 - r0;
+            if (kk > 0) {
+                // A[c0:pn, c0:c0+64] -= A[c0:pn, r0:c0] * A[c0:c0+64, r0:c0]^T
+                MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, pn - c0, IB, kk, A + c0 * lda + r0, lda, A + c0 * lda + r0, lda,
+                                          A + c0 * lda + c0, lda));
+            }
+            MGPI_TRY(mgpi_launch_potf2(ctx, A + c0 * lda + c0, lda, c0, ctx->d_diag + c0));
+            MGPI_TRY(mgpi_launch_trsm_rows(ctx, A + c0 * lda + c0, lda, A + (c0 + IB) * lda + c0, lda, pn - c0 - IB));
+        }
+        mgpi_prof_end(ctx, 1);
+        // ---- trailing update (lower tiles only): A22 -= P P^T, P = A[r0+w:pn, r0:r0+w]
+        const int64_t t = pn - r0 - w;
+        if (t > 0) {
+            mgpi_prof_begin(ctx);
+            const double* P = A + (r0 + w) * lda + r0;
+            MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 1, t, t, w, P, lda, P, lda, A + (r0 + w) * lda + (r0 + w), lda));
+            mgpi_prof_end(ctx, 0);
+        }
+    }
+
+    if (ctx->profile) {
+        MGPI_HIP_TRY(hipEventRecord(t1, ctx->stream));
+        MGPI_HIP_TRY(hipEventSynchronize(t1));
+        float f = 0.f;
+        MGPI_HIP_TRY(hipEventElapsedTime(&f, t0, t1));
+        ctx->prof[2].ms += f;
+        ctx->prof[2].launches += 1;
+        (void)hipEventDestroy(t0);
+        (void)hipEventDestroy(t1);
+    }
+
+    hipLaunchKernelGGL(logdiag_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, n, ctx->d_scal);
+    MGPI_HIP_TRY(hipGetLastError());
+    int info = 0;
+    double ld = 0.0;
+    MGPI_HIP_TRY(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MGPI_HIP_TRY(hipMemcpyAsync(&ld, ctx->d_scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (info != 0) {
+        K->factored = 0;
+        mgpi_set_error("covariance is not positive definite! (pivot %d)", info);
+        return info;
+    }
+    if (logdet) *logdet = 2.0 * ld;
+    K->factored = 1;
+    return 0;
+}
+
+// ---- multi-rhs triangular solves:  L X = B (trans = 0),  L^T X = B (trans = 1),  B is (n x m) wide ------
+static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ldb, int64_t ncols, int trans) {
+    const int64_t pn = Lm->prows <= Lm->pcols ? Lm->prows : mgpi_roundup(Lm->rows, IB);
+    const int64_t lda = Lm->ld, nb = ctx->nb;
+    const double* L = Lm->d;
+    const int64_t nc = mgpi_roundup(ncols, 64);
+    if (!trans) {
+        for (int64_t r0 = 0; r0 < pn; r0 += nb) {
+            const int64_t w = (pn - r0 < nb) ? (pn - r0) : nb;
+            for (int64_t c0 = r0; c0 < r0 + w; c0 += IB) {
+                const int64_t kk = c0 - r0;
+                if (kk > 0)   // B[c0:c0+64,:] -= L[c0:c0+64, r0:c0] * B[r0:c0,:]
+                    MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, IB, nc, kk, L + c0 * lda + r0, lda, B + r0 * ldb, ldb,
+                                              B + c0 * ldb, ldb));
+                MGPI_TRY(mgpi_launch_trsm_cols(ctx, L + c0 * lda + c0, lda, B + c0 * ldb, ldb, ncols, 0));
+            }
+            const int64_t t = pn - r0 - w;
+            if (t > 0)        // B[r0+w:,:] -= L[r0+w:, r0:r0+w] * B[r0:r0+w,:]
+                MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, t, nc, w, L + (r0 + w) * lda + r0, lda, B + r0 * ldb, ldb,
+                                          B + (r0 + w) * ldb, ldb));
+        }
+    } else {
+        const int64_t nblk = (pn + nb - 1) / nb;
+        for (int64_t b = nblk - 1; b >= 0; --b) {
+            const int64_t r0 = b * nb;
+            const int64_t w = (pn - r0 < nb) ? (pn - r0) : nb;
+            for (int64_t c0 = r0 + w - IB; c0 >= r0; c0 -= IB) {
+                const int64_t below = r0 + w - (c0 + IB);
+                if (below > 0)   // B[c0:c0+64,:] -= L[c0+64:r0+w, c0:c0+64]^T * B[c0+64:r0+w,:]
+                    MGPI_TRY(mgpi_launch_gemm(ctx, 1, 1, 0, IB, nc, below, L + (c0 + IB) * lda + c0, lda,
+                                              B + (c0 + IB) * ldb, ldb, B + c0 * ldb, ldb));
+                MGPI_TRY(mgpi_launch_trsm_cols(ctx, L + c0 * lda + c0, lda, B + c0 * ldb, ldb, ncols, 1));
+            }
+            if (r0 > 0)          // B[0:r0,:] -= L[r0:r0+w, 0:r0]^T * B[r0:r0+w,:]
+                MGPI_TRY(mgpi_launch_gemm(ctx, 1, 1, 0, r0, nc, w, L + r0 * lda, lda, B + r0 * ldb, ldb, B, ldb));
+        }
+    }
+    return 0;
+}
+
+int mgpi_trsm_raw(mgpi_ctx* ctx, const mgpi_mat* L, double* B, int64_t ldb, int64_t ncols, int trans) {
+    return trsm_blocked(ctx, L, B, ldb, ncols, trans);
+}
+
+extern "C" int mgpi_trsm_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* B, int trans) {
+    MGPI_REQUIRE(ctx && L && B, "mgpi_trsm_dev: null pointer");
+    MGPI_REQUIRE(L->factored, "mgpi_trsm_dev: L has not been factored by mgpi_potrf_dev");
+    if (!L->factored) return MGPI_ERR_STATE;
+    MGPI_REQUIRE(B->rows == L->rows, "mgpi_trsm_dev: B has %lld rows, L is %lld", (long long)B->rows, (long long)L->rows);
+    MGPI_REQUIRE(B->pcols % 64 == 0 && B->prows >= L->prows, "mgpi_trsm_dev: B must be a wide tile-padded matrix");
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    return trsm_blocked(ctx, L, B->d, B->ld, B->pcols, trans);
+}
+
+// ---- single right-hand side: HBM-bound blocked trsv ------------------------------------------------------
+// forward, diagonal nb-block: y_b = L_bb^-1 f_b.  One workgroup; 64-wide sub-blocks; the solved part of y in LDS.
+__global__ __launch_bounds__(256) void trsv_diag_fwd_kernel(const double* __restrict__ L, int64_t lda,
+                                                            double* __restrict__ y, int w) {
+    __shared__ double ys[4096];
+    __shared__ double Ls[IB][IB + 1];
+    __shared__ double sums[IB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < w; i += 256) ys[i] = y[i];
+    for (int c0 = 0; c0 < w; c0 += IB) {
+        // stage the 64x64 diagonal sub-block (coalesced)
+        for (int idx = tid; idx < IB * IB; idx += 256)
+            Ls[idx >> 6][idx & 63] = L[(int64_t)(c0 + (idx >> 6)) * lda + c0 + (idx & 63)];
+        __syncthreads();
+        // gemv part: sums[i] = sum_{m<c0} L[c0+i][m] y[m]; wave handles rows i = wave, wave+4, ..; lanes along m
+        for (int i = wave; i < IB; i += 4) {
+            const double* row = L + (int64_t)(c0 + i) * lda;
+            double s = 0.0;
+            for (int m = lane; m < c0; m += 64) s += row[m] * ys[m];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if (lane == 0) sums[i] = s;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            double b = ys[c0 + lane] - sums[lane];
+            // 64x64 substitution, column sweep: after y_k is known every later row subtracts L[i][k] y_k
+            for (int k = 0; k < IB; ++k) {
+                const double yk = __shfl(b, k, 64) / Ls[k][k];
+                if (lane == k) b = yk;
+                else if (lane > k) b -= Ls[lane][k] * yk;
+            }
+            ys[c0 + lane] = b;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < w; i += 256) y[i] = ys[i];
+}
+
+// backward, diagonal nb-block: x_b = L_bb^-T y_b
+__global__ __launch_bounds__(256) void trsv_diag_bwd_kernel(const double* __restrict__ L, int64_t lda,
+                                                            double* __restrict__ y, int w) {
+    __shared__ double ys[4096];
+    __shared__ double Ls[IB][IB + 1];
+    __shared__ double part[4][IB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < w; i += 256) ys[i] = y[i];
+    for (int c0 = w - IB; c0 >= 0; c0 -= IB) {
+        for (int idx = tid; idx < IB * IB; idx += 256)
+            Ls[idx >> 6][idx & 63] = L[(int64_t)(c0 + (idx >> 6)) * lda + c0 + (idx & 63)];
+        __syncthreads();
+        // x_j (j = c0+lane) needs sum_{i >= c0+64} L[i][j] x_i : column access, coalesced across lanes
+        double s = 0.0;
+        for (int i = c0 + IB + wave; i < w; i += 4) s += L[(int64_t)i * lda + c0 + lane] * ys[i];
+        part[wave][lane] = s;
+        __syncthreads();
+        if (wave == 0) {
+            double b = ys[c0 + lane] - (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+            for (int k = IB - 1; k >= 0; --k) {
+                const double xk = __shfl(b, k, 64) / Ls[k][k];
+                if (lane == k) b = xk;
+                else if (lane < k) b -= Ls[k][lane] * xk;
+            }
+            ys[c0 + lane] = b;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < w; i += 256) y[i] = ys[i];
+}
+
+// forward update: f[i] -= sum_{k<w} Lp[i][k] y[k]  for the rows below the block; one wave per row
+__global__ __launch_bounds__(256) void trsv_update_fwd_kernel(const double* __restrict__ Lp, int64_t lda,
+                                                              const double* __restrict__ y, int w,
+                                                              double* __restrict__ f, int64_t rows) {
+    __shared__ double ys[4096];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < w; i += 256) ys[i] = y[i];
+    __syncthreads();
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+        const double* row = Lp + r * lda;
+        double s = 0.0;
+        for (int k = 2 * lane; k < w; k += 128) {
+            const double2 v = *reinterpret_cast<const double2*>(row + k);
+            s += v.x * ys[k] + v.y * ys[k + 1];
+        }
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) f[r] -= s;
+    }
+}
+
+// backward update: y[j] -= sum_{i<w} Lb[i][j] x[i]  for the columns left of the block; 64 columns per workgroup
+__global__ __launch_bounds__(256) void trsv_update_bwd_kernel(const double* __restrict__ Lb, int64_t lda,
+                                                              const double* __restrict__ x, int w,
+                                                              double* __restrict__ y, int64_t cols) {
+    __shared__ double xs[4096];
+    __shared__ double part[4][IB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < w; i += 256) xs[i] = x[i];
+    __syncthreads();
+    const int64_t j = (int64_t)blockIdx.x * IB + lane;
+    double s = 0.0;
+    if (j < cols)
+        for (int i = wave; i < w; i += 4) s += Lb[(int64_t)i * lda + j] * xs[i];
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && j < cols) y[j] -= part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+}
+
+static int trsv_pair(mgpi_ctx* ctx, const mgpi_mat* Lm, double* v) {
+    const int64_t pn = Lm->prows <= Lm->pcols ? Lm->prows : mgpi_roundup(Lm->rows, IB);
+    const int64_t lda = Lm->ld;
+    const int64_t nb = ctx->nb;
+    const double* L = Lm->d;
+    for (int64_t r0 = 0; r0 < pn; r0 += nb) {   // L y = f
+        const int w = (int)((pn - r0 < nb) ? (pn - r0) : nb);
+        hipLaunchKernelGGL(trsv_diag_fwd_kernel, dim3(1), dim3(256), 0, ctx->stream, L + r0 * lda + r0, lda, v + r0, w);
+        const int64_t rows = pn - r0 - w;
+        if (rows > 0) {
+            int64_t blocks = (rows + 3) / 4;
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(trsv_update_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                               L + (r0 + w) * lda + r0, lda, v + r0, w, v + r0 + w, rows);
+        }
+    }
+    const int64_t nblk = (pn + nb - 1) / nb;
+    for (int64_t b = nblk - 1; b >= 0; --b) {   // L^T x = y
+        const int64_t r0 = b * nb;
+        const int w = (int)((pn - r0 < nb) ? (pn - r0) : nb);
+        hipLaunchKernelGGL(trsv_diag_bwd_kernel, dim3(1), dim3(256), 0, ctx->stream, L + r0 * lda + r0, lda, v + r0, w);
+        if (r0 > 0)
+            hipLaunchKernelGGL(trsv_update_bwd_kernel, dim3((unsigned)((r0 + IB - 1) / IB)), dim3(256), 0, ctx->stream,
+                               L + r0 * lda, lda, v + r0, w, v, r0);
+    }
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mgpi_potrs_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* B) {
+    MGPI_REQUIRE(ctx && L && B, "mgpi_potrs_dev: null pointer");
+    if (!L->factored) {
+        mgpi_set_error("mgpi_potrs_dev: L has not been factored by mgpi_potrf_dev");
+        return MGPI_ERR_STATE;
+    }
+    MGPI_REQUIRE(B->rows == L->rows, "mgpi_potrs_dev: B has %lld rows, L is %lld", (long long)B->rows, (long long)L->rows);
+    MGPI_REQUIRE(B->prows >= L->prows, "mgpi_potrs_dev: B row padding smaller than L's");
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    if (B->cols == 1 && B->ld == 1) return trsv_pair(ctx, L, B->d);
+    MGPI_REQUIRE(B->pcols % 64 == 0, "mgpi_potrs_dev: a multi-column B must be tile padded (cols > %d)", MGPI_MAX_D);
+    MGPI_TRY(trsm_blocked(ctx, L, B->d, B->ld, B->pcols, 0));
+    return trsm_blocked(ctx, L, B->d, B->ld, B->pcols, 1);
+}
+
+extern "C" int mgpi_potrs(mgpi_ctx* ctx, const mgpi_mat* L, const double* b, int64_t n, int nrhs, double* x) {
+    MGPI_REQUIRE(ctx && L && b && x, "mgpi_potrs: null pointer");
+    MGPI_REQUIRE(n == L->rows && nrhs >= 1, "mgpi_potrs: n=%lld does not match L (%lld) or nrhs < 1", (long long)n, (long long)L->rows);
+    mgpi_mat* B = nullptr;
+    // one rhs: a true vector (ld == 1); several: a wide padded matrix
+    int st = (nrhs == 1) ? mgpi_mat_alloc(ctx, n, 1, &B) : mgpi_mat_alloc_wide(ctx, n, nrhs, &B);
+    if (st == 0) st = mgpi_mat_upload(B, b, nrhs);
+    if (st == 0) st = mgpi_potrs_dev(ctx, L, B);
+    if (st == 0) st = mgpi_mat_download(B, x, nrhs);
+    mgpi_mat_free(B);
+    return st;
+}

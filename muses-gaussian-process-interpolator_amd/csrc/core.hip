@@ -1,0 +1,308 @@
+// Context, device matrices and error plumbing of libmgpi_hip.so.
+#include "mgpi_internal.h"
+#include <stdarg.h>
+#include <math.h>
+#include <new>
+
+static thread_local char g_err[512] = "";
+
+void mgpi_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* mgpi_last_error(void) { return g_err; }
+
+extern "C" int mgpi_device_count(int* count) {
+    MGPI_REQUIRE(count != nullptr, "mgpi_device_count: null pointer");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return 0;
+}
+
+extern "C" int mgpi_ctx_create(int device_id, int nb, mgpi_ctx** out) {
+    MGPI_REQUIRE(out != nullptr, "mgpi_ctx_create: null out pointer");
+    *out = nullptr;
+    if (nb == 0) nb = 512;
+    MGPI_REQUIRE(nb >= MGPI_TILE && nb % MGPI_TILE == 0 && nb <= 4096,
+                 "mgpi_ctx_create: nb=%d must be a multiple of %d in [%d, 4096]", nb, MGPI_TILE, MGPI_TILE);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        mgpi_set_error("mgpi_ctx_create: no HIP device available (%s); this library has no CPU fallback",
+                       e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return MGPI_ERR_HIP;
+    }
+    MGPI_REQUIRE(device_id >= 0 && device_id < ndev, "mgpi_ctx_create: device %d out of range [0,%d)", device_id, ndev);
+    MGPI_HIP_TRY(hipSetDevice(device_id));
+    mgpi_ctx* c = new (std::nothrow) mgpi_ctx();
+    if (!c) { mgpi_set_error("mgpi_ctx_create: out of host memory"); return MGPI_ERR_ALLOC; }
+    memset(c, 0, sizeof(*c));
+    c->device = device_id;
+    c->nb = nb;
+    MGPI_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    MGPI_HIP_TRY(hipEventCreate(&c->ev0));
+    MGPI_HIP_TRY(hipEventCreate(&c->ev1));
+    MGPI_HIP_TRY(hipEventCreate(&c->pev0));
+    MGPI_HIP_TRY(hipEventCreate(&c->pev1));
+    MGPI_HIP_TRY(hipMalloc((void**)&c->d_info, 64));
+    MGPI_HIP_TRY(hipMalloc((void**)&c->d_scal, 4096 * sizeof(double)));
+    MGPI_HIP_TRY(hipMemset(c->d_info, 0, 64));
+    *out = c;
+    return 0;
+}
+
+extern "C" int mgpi_ctx_destroy(mgpi_ctx* ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->work) (void)hipFree(ctx->work);
+    if (ctx->d_diag) (void)hipFree(ctx->d_diag);
+    (void)hipFree(ctx->d_info);
+    (void)hipFree(ctx->d_scal);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipEventDestroy(ctx->pev0);
+    (void)hipEventDestroy(ctx->pev1);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+extern "C" int mgpi_ctx_sync(mgpi_ctx* ctx) {
+    MGPI_REQUIRE(ctx != nullptr, "mgpi_ctx_sync: null ctx");
+    MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" void* mgpi_ctx_stream(mgpi_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" int mgpi_ctx_tic(mgpi_ctx* ctx) {
+    MGPI_REQUIRE(ctx != nullptr, "mgpi_ctx_tic: null ctx");
+    MGPI_HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    return 0;
+}
+
+extern "C" int mgpi_ctx_toc(mgpi_ctx* ctx, double* ms) {
+    MGPI_REQUIRE(ctx != nullptr && ms != nullptr, "mgpi_ctx_toc: null pointer");
+    MGPI_HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    MGPI_HIP_TRY(hipEventSynchronize(ctx->ev1));
+    float f = 0.f;
+    MGPI_HIP_TRY(hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+    *ms = (double)f;
+    return 0;
+}
+
+extern "C" int mgpi_ctx_set_profile(mgpi_ctx* ctx, int on) {
+    MGPI_REQUIRE(ctx != nullptr, "mgpi_ctx_set_profile: null ctx");
+    ctx->profile = on;
+    memset(ctx->prof, 0, sizeof(ctx->prof));
+    return 0;
+}
+
+extern "C" int mgpi_ctx_get_profile(mgpi_ctx* ctx, int which, double* ms, int64_t* launches) {
+    MGPI_REQUIRE(ctx != nullptr && which >= 0 && which < 3, "mgpi_ctx_get_profile: bad argument");
+    if (ms) *ms = ctx->prof[which].ms;
+    if (launches) *launches = ctx->prof[which].launches;
+    return 0;
+}
+
+// per-launch HIP-event timing (synchronous; only when profiling is switched on)
+void mgpi_prof_begin(mgpi_ctx* ctx) {
+    if (ctx->profile) (void)hipEventRecord(ctx->pev0, ctx->stream);
+}
+void mgpi_prof_end(mgpi_ctx* ctx, int slot) {
+    if (!ctx->profile) return;
+    (void)hipEventRecord(ctx->pev1, ctx->stream);
+    (void)hipEventSynchronize(ctx->pev1);
+    float f = 0.f;
+    (void)hipEventElapsedTime(&f, ctx->pev0, ctx->pev1);
+    ctx->prof[slot].ms += f;
+    ctx->prof[slot].launches += 1;
+}
+
+int mgpi_ensure_work(mgpi_ctx* ctx, size_t bytes) {
+    if (ctx->work_bytes >= bytes) return 0;
+    if (ctx->work) {
+        MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        MGPI_HIP_TRY(hipFree(ctx->work));
+        ctx->work = nullptr;
+        ctx->work_bytes = 0;
+    }
+    hipError_t e = hipMalloc((void**)&ctx->work, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        mgpi_set_error("workspace allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        return MGPI_ERR_ALLOC;
+    }
+    ctx->work_bytes = bytes;
+    return 0;
+}
+
+// ---- matrices ---------------------------------------------------------------------------
+
+static int mat_alloc_impl(mgpi_ctx* ctx, int64_t rows, int64_t cols, int wide, mgpi_mat** out) {
+    MGPI_REQUIRE(ctx != nullptr && out != nullptr, "mgpi_mat_alloc: null pointer");
+    MGPI_REQUIRE(rows >= 1 && cols >= 1, "mgpi_mat_alloc: empty shape %lld x %lld", (long long)rows, (long long)cols);
+    *out = nullptr;
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    mgpi_mat* m = new (std::nothrow) mgpi_mat();
+    if (!m) { mgpi_set_error("mgpi_mat_alloc: out of host memory"); return MGPI_ERR_ALLOC; }
+    m->ctx = ctx;
+    m->rows = rows;
+    m->cols = cols;
+    m->prows = mgpi_roundup(rows, MGPI_TILE);
+    // narrow matrices (coordinates, vectors) keep their natural row stride; wide ones are padded to the tile
+    m->pcols = (!wide && cols <= MGPI_MAX_D) ? cols : mgpi_roundup(cols, MGPI_TILE);
+    m->ld = m->pcols;
+    m->owns = 1;
+    m->factored = 0;
+    size_t bytes = (size_t)m->prows * (size_t)m->pcols * sizeof(double);
+    hipError_t e = hipMalloc((void**)&m->d, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        mgpi_set_error("mgpi_mat_alloc: hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        delete m;
+        return MGPI_ERR_ALLOC;
+    }
+    MGPI_HIP_TRY(hipMemsetAsync(m->d, 0, bytes, ctx->stream));
+    *out = m;
+    return 0;
+}
+
+extern "C" int mgpi_mat_alloc(mgpi_ctx* ctx, int64_t rows, int64_t cols, mgpi_mat** out) {
+    return mat_alloc_impl(ctx, rows, cols, 0, out);
+}
+
+extern "C" int mgpi_mat_alloc_wide(mgpi_ctx* ctx, int64_t rows, int64_t cols, mgpi_mat** out) {
+    return mat_alloc_impl(ctx, rows, cols, 1, out);
+}
+
+extern "C" int mgpi_mat_free(mgpi_mat* m) {
+    if (!m) return 0;
+    if (m->owns && m->d) {
+        (void)hipSetDevice(m->ctx->device);
+        (void)hipStreamSynchronize(m->ctx->stream);
+        (void)hipFree(m->d);
+    }
+    delete m;
+    return 0;
+}
+
+extern "C" int mgpi_mat_view(const mgpi_mat* m, int64_t r0, int64_t c0, int64_t rows, int64_t cols, mgpi_mat** out) {
+    MGPI_REQUIRE(m != nullptr && out != nullptr, "mgpi_mat_view: null pointer");
+    MGPI_REQUIRE(r0 >= 0 && c0 >= 0 && rows >= 1 && cols >= 1 && r0 + rows <= m->prows && c0 + cols <= m->pcols,
+                 "mgpi_mat_view: window (%lld,%lld)+(%lld x %lld) outside padded %lld x %lld", (long long)r0,
+                 (long long)c0, (long long)rows, (long long)cols, (long long)m->prows, (long long)m->pcols);
+    mgpi_mat* v = new (std::nothrow) mgpi_mat();
+    if (!v) { mgpi_set_error("mgpi_mat_view: out of host memory"); return MGPI_ERR_ALLOC; }
+    *v = *m;
+    v->rows = rows;
+    v->cols = cols;
+    v->prows = rows;   // a view exposes exactly its window
+    v->pcols = cols;
+    v->d = m->d + r0 * m->ld + c0;
+    v->owns = 0;
+    *out = v;
+    return 0;
+}
+
+extern "C" int mgpi_mat_shape(const mgpi_mat* m, int64_t* rows, int64_t* cols, int64_t* ld) {
+    MGPI_REQUIRE(m != nullptr, "mgpi_mat_shape: null matrix");
+    if (rows) *rows = m->rows;
+    if (cols) *cols = m->cols;
+    if (ld) *ld = m->ld;
+    return 0;
+}
+
+extern "C" void* mgpi_mat_devptr(const mgpi_mat* m) { return m ? (void*)m->d : nullptr; }
+
+extern "C" int mgpi_mat_upload(mgpi_mat* m, const double* host, int64_t host_ld) {
+    MGPI_REQUIRE(m != nullptr && host != nullptr, "mgpi_mat_upload: null pointer");
+    MGPI_REQUIRE(host_ld >= m->cols, "mgpi_mat_upload: host_ld %lld < cols %lld", (long long)host_ld, (long long)m->cols);
+    MGPI_HIP_TRY(hipSetDevice(m->ctx->device));
+    MGPI_HIP_TRY(hipMemcpy2DAsync(m->d, (size_t)m->ld * sizeof(double), host, (size_t)host_ld * sizeof(double),
+                                  (size_t)m->cols * sizeof(double), (size_t)m->rows, hipMemcpyHostToDevice,
+                                  m->ctx->stream));
+    MGPI_HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    m->factored = 0;
+    return 0;
+}
+
+extern "C" int mgpi_mat_download(const mgpi_mat* m, double* host, int64_t host_ld) {
+    MGPI_REQUIRE(m != nullptr && host != nullptr, "mgpi_mat_download: null pointer");
+    MGPI_REQUIRE(host_ld >= m->cols, "mgpi_mat_download: host_ld %lld < cols %lld", (long long)host_ld, (long long)m->cols);
+    MGPI_HIP_TRY(hipSetDevice(m->ctx->device));
+    MGPI_HIP_TRY(hipMemcpy2DAsync(host, (size_t)host_ld * sizeof(double), m->d, (size_t)m->ld * sizeof(double),
+                                  (size_t)m->cols * sizeof(double), (size_t)m->rows, hipMemcpyDeviceToHost,
+                                  m->ctx->stream));
+    MGPI_HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    return 0;
+}
+
+extern "C" int mgpi_mat_copy(mgpi_ctx* ctx, const mgpi_mat* src, mgpi_mat* dst) {
+    MGPI_REQUIRE(ctx && src && dst, "mgpi_mat_copy: null pointer");
+    MGPI_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, "mgpi_mat_copy: shape mismatch");
+    int64_t r = src->prows < dst->prows ? src->prows : dst->prows;
+    int64_t c = src->pcols < dst->pcols ? src->pcols : dst->pcols;
+    MGPI_HIP_TRY(hipMemcpy2DAsync(dst->d, (size_t)dst->ld * sizeof(double), src->d, (size_t)src->ld * sizeof(double),
+                                  (size_t)c * sizeof(double), (size_t)r, hipMemcpyDeviceToDevice, ctx->stream));
+    dst->factored = src->factored;
+    return 0;
+}
+
+// upper(i,j) = lower(j,i); 32x32 tiles through LDS so both sides stay coalesced
+__global__ __launch_bounds__(256) void symmetrize_kernel(double* a, int64_t ld, int64_t n) {
+    __shared__ double tile[32][33];
+    const int bi = blockIdx.y, bj = blockIdx.x;   // source tile (bi, bj) with bj <= bi
+    if (bj > bi) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        int64_t i = (int64_t)bi * 32 + r, j = (int64_t)bj * 32 + tx;
+        tile[r][tx] = (i < n && j < n) ? a[i * ld + j] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        // destination element (row = bj*32 + r, col = bi*32 + tx) = source (bi*32+tx, bj*32+r)
+        int64_t i = (int64_t)bj * 32 + r, j = (int64_t)bi * 32 + tx;
+        if (i < n && j < n && j > i) a[i * ld + j] = tile[tx][r];
+    }
+}
+
+extern "C" int mgpi_mat_symmetrize(mgpi_ctx* ctx, mgpi_mat* m) {
+    MGPI_REQUIRE(ctx && m, "mgpi_mat_symmetrize: null pointer");
+    MGPI_REQUIRE(m->rows == m->cols, "mgpi_mat_symmetrize: matrix is not square");
+    unsigned nt = (unsigned)((m->rows + 31) / 32);
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(nt, nt), dim3(256), 0, ctx->stream, m->d, m->ld, m->rows);
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mgpi_make_terms(const mgpi_kernel_desc* terms, int nterms, int d, mgpi_terms_dev* out) {
+    MGPI_REQUIRE(terms != nullptr && out != nullptr, "kernel terms: null pointer");
+    MGPI_REQUIRE(nterms >= 1 && nterms <= MGPI_MAX_TERMS, "kernel terms: nterms=%d outside [1,%d]", nterms, MGPI_MAX_TERMS);
+    MGPI_REQUIRE(d >= 1 && d <= MGPI_MAX_D, "kernel terms: d=%d outside [1,%d]", d, MGPI_MAX_D);
+    memset(out, 0, sizeof(*out));
+    out->nterms = nterms;
+    out->d = d;
+    for (int t = 0; t < nterms; ++t) {
+        MGPI_REQUIRE(terms[t].type == MGPI_TERM_SE || terms[t].type == MGPI_TERM_WHITE,
+                     "kernel terms: term %d has unsupported type %d", t, terms[t].type);
+        out->type[t] = terms[t].type;
+        out->sig2[t] = terms[t].sigma * terms[t].sigma;          // sigma**2
+        if (terms[t].type == MGPI_TERM_SE)
+            for (int k = 0; k < d; ++k) {
+                // 1/length**2 ; a zero length gives inf, like the reference's division
+                out->inv_l2[t][k] = 1.0 / (terms[t].length[k] * terms[t].length[k]);
+            }
+    }
+    return 0;
+}

@@ -1,0 +1,180 @@
+// Kernel-matrix build: the device form of Interpolator._x2cov (mgpi/interpolators.py:208-300) and of the
+// row-paired Kernel.cov (mgpi/kernels.py:89-93).  The reference materialises the n1*n2 row pairs; here each
+// workgroup owns one 64x64 output tile, stages the two coordinate slabs in LDS as SoA and never forms pairs.
+#include "cov_device.h"
+
+#define COV_T 64   // output tile edge
+
+// out[i][j] = k(x1_i, x2_j) for i < n1, j < n2; padded entries (i >= n1 or j >= n2, up to p1 x p2) are written
+// as 0, or as the identity when pad_identity (so that the padded K stays positive definite, its Cholesky
+// factor is [[L,0],[0,I]] and logdet is unchanged).
+template <int D>
+__global__ __launch_bounds__(256) void cov_tile_kernel(mgpi_terms_dev t, const double* __restrict__ x1, int64_t ldx1,
+                                                       int64_t n1, const double* __restrict__ x2, int64_t ldx2,
+                                                       int64_t n2, int lower_only, int pad_identity,
+                                                       double* __restrict__ out, int64_t ldo) {
+    constexpr int DD = (D > 0) ? D : MGPI_MAX_D;
+    __shared__ double s1[DD][COV_T];
+    __shared__ __attribute__((aligned(16))) double s2[DD][COV_T];
+    const int nd = (D > 0) ? D : t.d;
+    const int64_t row0 = (int64_t)blockIdx.y * COV_T, col0 = (int64_t)blockIdx.x * COV_T;
+    if (lower_only && col0 > row0) return;   // strictly-upper tile: potrf never reads it
+
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < COV_T * nd; idx += 256) {
+        const int r = idx / nd, k = idx - r * nd;
+        s1[k][r] = (row0 + r < n1) ? x1[(row0 + r) * ldx1 + k] : 0.0;
+        s2[k][r] = (col0 + r < n2) ? x2[(col0 + r) * ldx2 + k] : 0.0;
+    }
+    __syncthreads();
+
+    const int tx = tid & 15, ty = tid >> 4;   // 16 x 16 threads; each owns 4 rows x (2 x 2) columns
+    double a[4][DD], b[4][DD];
+#pragma unroll
+    for (int k = 0; k < DD; ++k) {
+        if (k < nd) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r][k] = s1[k][ty * 4 + r];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const double2 v = *reinterpret_cast<const double2*>(&s2[k][2 * tx + 32 * c]);
+                b[2 * c][k] = v.x;
+                b[2 * c + 1][k] = v.y;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = row0 + ty * 4 + r;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int64_t j = col0 + 2 * tx + 32 * c;
+            double2 v;
+            v.x = mgpi_cov_entry<D>(t, a[r], b[2 * c]);
+            v.y = mgpi_cov_entry<D>(t, a[r], b[2 * c + 1]);
+            if (i >= n1 || j >= n2) v.x = (pad_identity && i == j) ? 1.0 : 0.0;
+            if (i >= n1 || j + 1 >= n2) v.y = (pad_identity && i == j + 1) ? 1.0 : 0.0;
+            *reinterpret_cast<double2*>(&out[i * ldo + j]) = v;
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void cov_paired_kernel(mgpi_terms_dev t, const double* __restrict__ x1,
+                                                         const double* __restrict__ x2, int64_t p,
+                                                         double* __restrict__ out) {
+    constexpr int DD = (D > 0) ? D : MGPI_MAX_D;
+    const int nd = (D > 0) ? D : t.d;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p; i += (int64_t)gridDim.x * 256) {
+        double a[DD], b[DD];
+#pragma unroll
+        for (int k = 0; k < DD; ++k)
+            if (k < nd) {
+                a[k] = x1[i * nd + k];
+                b[k] = x2[i * nd + k];
+            }
+        out[i] = mgpi_cov_entry<D>(t, a, b);
+    }
+}
+
+int mgpi_launch_cov(mgpi_ctx* ctx, const mgpi_terms_dev& t, const double* x1, int64_t ldx1, int64_t n1, int64_t p1,
+                    const double* x2, int64_t ldx2, int64_t n2, int64_t p2, int symmetric, int lower_only,
+                    int pad_identity, double* out, int64_t ldo) {
+    (void)symmetric;
+    MGPI_REQUIRE(p1 % COV_T == 0 && p2 % COV_T == 0, "cov: padded output %lld x %lld is not a multiple of %d",
+                 (long long)p1, (long long)p2, COV_T);
+    MGPI_REQUIRE(p1 / COV_T <= 65535, "cov: too many row tiles");
+    dim3 grid((unsigned)(p2 / COV_T), (unsigned)(p1 / COV_T)), block(256);
+#define MGPI_COV_CASE(DV)                                                                                     \
+    case DV:                                                                                                  \
+        hipLaunchKernelGGL(cov_tile_kernel<DV>, grid, block, 0, ctx->stream, t, x1, ldx1, n1, x2, ldx2, n2,  \
+                           lower_only, pad_identity, out, ldo);                                               \
+        break;
+    switch (t.d) {
+        MGPI_COV_CASE(1)
+        MGPI_COV_CASE(2)
+        MGPI_COV_CASE(3)
+        MGPI_COV_CASE(4)
+        MGPI_COV_CASE(5)
+        MGPI_COV_CASE(6)
+        default:
+            hipLaunchKernelGGL(cov_tile_kernel<0>, grid, block, 0, ctx->stream, t, x1, ldx1, n1, x2, ldx2, n2,
+                               lower_only, pad_identity, out, ldo);
+    }
+#undef MGPI_COV_CASE
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mgpi_cov_matrix_dev(mgpi_ctx* ctx, const mgpi_mat* X1, const mgpi_mat* X2, const mgpi_kernel_desc* terms,
+                                   int nterms, int lower_only, mgpi_mat* out) {
+    MGPI_REQUIRE(ctx && X1 && out, "mgpi_cov_matrix_dev: null pointer");
+    const mgpi_mat* Xb = X2 ? X2 : X1;
+    MGPI_REQUIRE(X1->cols == Xb->cols, "conflicting number of dimensions for x1 and x2 (%lld vs %lld)",
+                 (long long)X1->cols, (long long)Xb->cols);   // interpolators.py:219
+    MGPI_REQUIRE(out->rows == X1->rows && out->cols == Xb->rows, "mgpi_cov_matrix_dev: out is %lld x %lld, expected %lld x %lld",
+                 (long long)out->rows, (long long)out->cols, (long long)X1->rows, (long long)Xb->rows);
+    MGPI_REQUIRE(!lower_only || X2 == nullptr, "mgpi_cov_matrix_dev: lower_only needs the symmetric form (X2 == NULL)");
+    MGPI_REQUIRE(out->pcols % COV_T == 0, "mgpi_cov_matrix_dev: out must be a wide (tile-padded) matrix, cols > %d", MGPI_MAX_D);
+    mgpi_terms_dev t;
+    MGPI_TRY(mgpi_make_terms(terms, nterms, (int)X1->cols, &t));
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    const int sym = (X2 == nullptr);
+    out->factored = 0;
+    return mgpi_launch_cov(ctx, t, X1->d, X1->ld, X1->rows, out->prows, Xb->d, Xb->ld, Xb->rows, out->pcols, sym,
+                           lower_only, /*pad_identity=*/sym, out->d, out->ld);
+}
+
+extern "C" int mgpi_cov_matrix(mgpi_ctx* ctx, const double* x1, int64_t n1, const double* x2, int64_t n2, int d,
+                               const mgpi_kernel_desc* terms, int nterms, double* out) {
+    MGPI_REQUIRE(ctx && x1 && out, "mgpi_cov_matrix: null pointer");
+    MGPI_REQUIRE(n1 >= 1 && (x2 == nullptr || n2 >= 1), "mgpi_cov_matrix: empty input");
+    if (x2 == nullptr) n2 = n1;
+    mgpi_mat *X1 = nullptr, *X2 = nullptr, *K = nullptr;
+    int st = mgpi_mat_alloc(ctx, n1, d, &X1);
+    if (st == 0) st = mgpi_mat_upload(X1, x1, d);
+    if (st == 0 && x2) st = mgpi_mat_alloc(ctx, n2, d, &X2);
+    if (st == 0 && x2) st = mgpi_mat_upload(X2, x2, d);
+    if (st == 0) st = mgpi_mat_alloc_wide(ctx, n1, n2, &K);
+    if (st == 0) st = mgpi_cov_matrix_dev(ctx, X1, X2, terms, nterms, 0, K);
+    if (st == 0) st = mgpi_mat_download(K, out, n2);
+    mgpi_mat_free(X1);
+    mgpi_mat_free(X2);
+    mgpi_mat_free(K);
+    return st;
+}
+
+extern "C" int mgpi_cov_paired(mgpi_ctx* ctx, const double* x1, const double* x2, int64_t p, int d,
+                               const mgpi_kernel_desc* terms, int nterms, double* out) {
+    MGPI_REQUIRE(ctx && x1 && x2 && out, "mgpi_cov_paired: null pointer");
+    MGPI_REQUIRE(p >= 1, "mgpi_cov_paired: empty input");
+    mgpi_terms_dev t;
+    MGPI_TRY(mgpi_make_terms(terms, nterms, d, &t));
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    const size_t xb = (size_t)p * d * sizeof(double), ob = (size_t)p * sizeof(double);
+    MGPI_TRY(mgpi_ensure_work(ctx, 2 * xb + ob));
+    double* d1 = ctx->work;
+    double* d2 = d1 + (size_t)p * d;
+    double* dout = d2 + (size_t)p * d;
+    MGPI_HIP_TRY(hipMemcpyAsync(d1, x1, xb, hipMemcpyHostToDevice, ctx->stream));
+    MGPI_HIP_TRY(hipMemcpyAsync(d2, x2, xb, hipMemcpyHostToDevice, ctx->stream));
+    int64_t blocks = (p + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+#define MGPI_PAIR_CASE(DV)                                                                                          \
+    case DV:                                                                                                        \
+        hipLaunchKernelGGL(cov_paired_kernel<DV>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, t, d1, d2, p, dout); \
+        break;
+    switch (d) {
+        MGPI_PAIR_CASE(1)
+        MGPI_PAIR_CASE(2)
+        MGPI_PAIR_CASE(3)
+        MGPI_PAIR_CASE(4)
+        default:
+            hipLaunchKernelGGL(cov_paired_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, t, d1, d2, p, dout);
+    }
+#undef MGPI_PAIR_CASE
+    MGPI_HIP_TRY(hipGetLastError());
+    MGPI_HIP_TRY(hipMemcpyAsync(out, dout, ob, hipMemcpyDeviceToHost, ctx->stream));
+    MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}

@@ -1,0 +1,101 @@
+// Internal declarations shared by the HIP translation units of libmgpi_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "mgpi_hip.h"
+
+#define MGPI_TILE   128      // padding granule of matrix dims and the gemm macro-tile
+#define MGPI_IB      64      // inner (panel) block of the two-level Cholesky / trsm
+
+struct mgpi_prof_slot { double ms; int64_t launches; };
+
+struct mgpi_ctx {
+    int device;
+    int nb;                       // outer Cholesky block
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;          // tic/toc
+    hipEvent_t pev0, pev1;        // per-kernel profiling
+    int profile;
+    mgpi_prof_slot prof[3];
+    int* d_info;                  // device: first failing pivot (0 = none)
+    double* d_scal;               // device scratch scalars (logdet partials etc.), 4096 doubles
+    double* d_diag;               // diag(K) before factoring (pivot threshold), grown on demand
+    int64_t diag_len;
+    double* work;                 // device workspace, grown on demand
+    size_t work_bytes;
+};
+
+struct mgpi_mat {
+    mgpi_ctx* ctx;
+    int64_t rows, cols;           // logical shape
+    int64_t prows, pcols;         // padded (allocated) shape; pcols == ld for owners
+    int64_t ld;                   // row stride in doubles
+    double* d;                    // device pointer to element (0,0)
+    int owns;
+    int factored;                 // set by potrf
+};
+
+// ---- error plumbing -------------------------------------------------------------------
+void mgpi_set_error(const char* fmt, ...);
+#define MGPI_HIP_TRY(expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            mgpi_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                           __LINE__);                                                        \
+            return MGPI_ERR_HIP;                                                             \
+        }                                                                                    \
+    } while (0)
+#define MGPI_REQUIRE(cond, ...)                                                              \
+    do {                                                                                     \
+        if (!(cond)) {                                                                       \
+            mgpi_set_error(__VA_ARGS__);                                                     \
+            return MGPI_ERR_ARG;                                                             \
+        }                                                                                    \
+    } while (0)
+#define MGPI_TRY(expr)                                                                       \
+    do {                                                                                     \
+        int _s = (expr);                                                                     \
+        if (_s != 0) return _s;                                                              \
+    } while (0)
+
+static inline int64_t mgpi_roundup(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+int mgpi_ensure_work(mgpi_ctx* ctx, size_t bytes);
+
+// ---- device-side kernel descriptor (passed by value as a kernel argument) -------------------
+struct mgpi_terms_dev {
+    int nterms;
+    int d;
+    int type[MGPI_MAX_TERMS];
+    double sig2[MGPI_MAX_TERMS];                    // sigma**2              (kernels.py:131,185)
+    double inv_l2[MGPI_MAX_TERMS][MGPI_MAX_D];      // 1/length_d**2         (kernels.py:185)
+};
+int mgpi_make_terms(const mgpi_kernel_desc* terms, int nterms, int d, mgpi_terms_dev* out);
+
+// ---- launchers (each enqueues on ctx->stream, no host sync) ----------------------------------
+// raw-pointer gemm:  C(m x n, ldc) -= opA(A) * opB(B), contraction length k
+//   a_kmajor == 0: A is (m x k) row-major (lda);  a_kmajor == 1: A is stored (k x m) row-major
+//   b_kmajor == 0: B is (n x k) row-major (ldb);  b_kmajor == 1: B is stored (k x n) row-major
+//   m multiple of 64, n multiple of 64, k multiple of 16.  lower_only: m == n, tiles with j <= i.
+int mgpi_launch_gemm(mgpi_ctx* ctx, int a_kmajor, int b_kmajor, int lower_only,
+                     int64_t m, int64_t n, int64_t k,
+                     const double* A, int64_t lda, const double* B, int64_t ldb,
+                     double* C, int64_t ldc);
+
+int mgpi_launch_cov(mgpi_ctx* ctx, const mgpi_terms_dev& t,
+                    const double* x1, int64_t ldx1, int64_t n1, int64_t p1,
+                    const double* x2, int64_t ldx2, int64_t n2, int64_t p2,
+                    int symmetric, int lower_only, int pad_identity,
+                    double* out, int64_t ldo);
+
+// panel pieces of the Cholesky (chol.hip)
+int mgpi_launch_potf2(mgpi_ctx* ctx, double* A, int64_t lda, int64_t pivot_base, const double* diag0);   // 64x64 in place
+int mgpi_launch_trsm_rows(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double* A, int64_t lda, int64_t rows);
+// multi-rhs 64-row block solves on B (64 x n): trans=0: L_jj^-1 B, trans=1: L_jj^-T B
+int mgpi_launch_trsm_cols(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double* B, int64_t ldb, int64_t n, int trans);
+
+void mgpi_prof_begin(mgpi_ctx* ctx);
+void mgpi_prof_end(mgpi_ctx* ctx, int slot);

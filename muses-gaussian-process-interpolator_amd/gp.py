@@ -1,0 +1,275 @@
+"""Dense Gaussian-process regression on one MI355X: the host-side mirror of the reference's
+``Interpolator`` (mgpi/interpolators.py:47-343).
+
+Drop-in surface (same names, argument order and meaning, same exceptions):
+
+    Interpolator(kernel, nugget=None)                                   interpolators.py:52
+    .update(*args, **kw) / .update_nugget(*args, **kw)                  :56-66
+    .compress(source_x, source_f, verbose=False, Verbose=False) -> (N,)           :72
+    .predict(target_x, source_x, compressed, verbose=False, Verbose=False) -> (M,) :109
+    .condition(target_x, source_x, source_f, verbose=False, Verbose=False) -> (mean (M,), cov (M,M))  :136
+    ._x2cov(x1, x2, kernel, verbose=False) -> (n1, n2)   [staticmethod]  :208
+    .loglikelihood(source_x, source_f, verbose=False) -> float          :331
+    .rvs(target_x, source_x, source_f, size=1) -> (size, M)             :306
+
+Additive (not in the reference): ``condition_diag`` (mean + pointwise variance without the M x M
+matrix - the only way to ask for a variance at 1e6 query points), ``fit`` / ``FittedGP`` (keeps x, L and
+alpha resident in HBM between calls), ``sample`` (alias of rvs).
+
+Where the reference calls ``np.linalg.inv`` (:92,:179,:343) this module factors K = L L^T on the GPU
+(mgpi_potrf_dev) and solves with L; where it materialises n1*n2 row pairs (:247-294) the GPU builds
+the matrix tile by tile (mgpi_cov_matrix_dev).  All O(N^2) and O(N^3) arithmetic is in
+libmgpi_hip.so; there is no numpy fallback.
+"""
+import ctypes
+import time
+
+import numpy as np
+
+from . import _lib
+from .kernel_objects import Kernel
+
+__all__ = ['Interpolator', 'FittedGP']
+
+
+def _flatten(kernel, nugget=None):
+    """ordered summands of kernel (+ nugget): what ``kernel+nugget`` means at interpolators.py:84,169,337"""
+    terms = list(kernel.terms())
+    if nugget is not None:
+        terms.extend(nugget.terms())
+    return terms
+
+
+class _Stage(object):
+    """prints the reference's stage banners and timings (interpolators.py:78-102 etc.)"""
+
+    def __init__(self, ctx, enabled):
+        self.ctx = ctx
+        self.enabled = enabled
+        self.t0 = None
+
+    def begin(self, text):
+        if self.enabled:
+            print(text)
+            self.ctx.sync()
+            self.t0 = time.time()
+
+    def end(self):
+        if self.enabled:
+            self.ctx.sync()
+            print('    time : %.6f sec' % (time.time() - self.t0))
+
+
+class FittedGP(object):
+    """x, the Cholesky factor of K(x,x; kernel+nugget) and (optionally) alpha, resident in HBM"""
+
+    def __init__(self, ctx, source_x, kernel_terms, solve_terms, stage=None):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        x = _lib.as_f64(source_x, ndim=2)
+        self.n, self.d = x.shape
+        self.kernel_terms = list(kernel_terms)     # K*, K** : kernel only
+        self.solve_terms = list(solve_terms)       # K       : kernel + nugget
+        self._kdesc = _lib.make_terms(self.kernel_terms)
+        self._sdesc = _lib.make_terms(self.solve_terms)
+        self.X = _lib.DeviceMatrix.from_host(ctx, x)
+        self.L = _lib.DeviceMatrix(ctx, self.n, self.n, wide=True)
+        self.alpha = None
+        self.logdet = None
+        stage = stage or _Stage(ctx, False)
+
+        stage.begin('constructing %d x %d source-source covariance matrix' % (self.n, self.n))
+        # lower tiles only: the factorisation never reads the strict upper triangle
+        _lib.check(self.lib.mgpi_cov_matrix_dev(ctx.handle, self.X.handle, None, self._sdesc[0], self._sdesc[1], 1,
+                                                self.L.handle))
+        stage.end()
+
+        stage.begin('inverting source-source covariance matrix')
+        logdet = ctypes.c_double(0.0)
+        _lib.check(self.lib.mgpi_potrf_dev(ctx.handle, self.L.handle, ctypes.byref(logdet)))
+        self.logdet = logdet.value
+        stage.end()
+
+    # alpha = K^-1 f
+    def solve(self, source_f):
+        f = _lib.as_f64(source_f).reshape(-1)
+        assert len(f) == self.n, 'source_f has %d entries for %d source points' % (len(f), self.n)
+        self.alpha = _lib.DeviceMatrix.from_host(self.ctx, f)
+        _lib.check(self.lib.mgpi_potrs_dev(self.ctx.handle, self.L.handle, self.alpha.handle))
+        return self.alpha
+
+    def set_alpha(self, compressed):
+        a = _lib.as_f64(compressed).reshape(-1)
+        assert len(a) == self.n, 'compressed has %d entries for %d source points' % (len(a), self.n)
+        self.alpha = _lib.DeviceMatrix.from_host(self.ctx, a)
+
+    def _targets(self, target_x):
+        xs = _lib.as_f64(target_x, ndim=2)
+        assert xs.shape[1] == self.d, 'conflicting number of dimensions for x1 and x2'   # interpolators.py:219
+        return _lib.DeviceMatrix.from_host(self.ctx, xs)
+
+    def mean_dev(self, XS):
+        out = _lib.DeviceMatrix(self.ctx, XS.rows, 1)
+        _lib.check(self.lib.mgpi_predict_mean_dev(self.ctx.handle, XS.handle, self.X.handle, self._kdesc[0],
+                                                  self._kdesc[1], self.alpha.handle, out.handle))
+        return out
+
+    def var_dev(self, XS, m_slab=0):
+        out = _lib.DeviceMatrix(self.ctx, XS.rows, 1)
+        _lib.check(self.lib.mgpi_predict_var_dev(self.ctx.handle, XS.handle, self.X.handle, self._kdesc[0],
+                                                 self._kdesc[1], self.L.handle, int(m_slab), out.handle))
+        return out
+
+    def cov_dev(self, XS):
+        m = XS.rows
+        out = _lib.DeviceMatrix(self.ctx, m, m, wide=True)
+        _lib.check(self.lib.mgpi_condition_cov_dev(self.ctx.handle, XS.handle, self.X.handle, self._kdesc[0],
+                                                   self._kdesc[1], self.L.handle, out.handle))
+        return out
+
+    def mean(self, target_x):
+        return self.mean_dev(self._targets(target_x)).to_host().reshape(-1)
+
+    def variance(self, target_x, m_slab=0):
+        return self.var_dev(self._targets(target_x), m_slab=m_slab).to_host().reshape(-1)
+
+    def covariance(self, target_x):
+        return self.cov_dev(self._targets(target_x)).to_host()
+
+
+class Interpolator(object):
+    """general Gaussian-process regression, no structure assumed in the covariance
+    (the reference's class of the same name, interpolators.py:47)"""
+
+    def __init__(self, kernel, nugget=None, context=None):
+        self.kernel = kernel
+        self.nugget = nugget
+        self._context = context
+
+    @property
+    def context(self):
+        return self._context if self._context is not None else _lib.default_context()
+
+    def update(self, *args, **kwargs):
+        """update the kernel's parameters (interpolators.py:56-59)"""
+        return self.kernel.update(*args, **kwargs)
+
+    def update_nugget(self, *args, **kwargs):
+        """update the nugget's parameters (interpolators.py:61-66)"""
+        if self.nugget is None:
+            raise RuntimeError('cannot update nugget=None')
+        self.nugget.update(*args, **kwargs)
+
+    #--- device-resident fit (additive)
+
+    def fit(self, source_x, source_f=None, verbose=False):
+        """build + factor K(x,x; kernel+nugget) on the GPU and (if source_f is given) solve for alpha"""
+        stage = _Stage(self.context, verbose)
+        gp = FittedGP(self.context, source_x, _flatten(self.kernel), _flatten(self.kernel, self.nugget), stage=stage)
+        if source_f is not None:
+            stage.begin('compressing observations')
+            gp.solve(source_f)
+            stage.end()
+        return gp
+
+    def _fit_checked(self, source_x, source_f, verbose):
+        try:
+            return self.fit(source_x, source_f, verbose=verbose)
+        except _lib.NotPositiveDefinite as err:
+            # the reference's inv() raises LinAlgError on a singular K; a Cholesky also rejects
+            # indefinite K, which inv() would silently accept
+            raise np.linalg.LinAlgError('source-source covariance is not positive definite (pivot %d)' % err.pivot)
+
+    #--- compress / predict (interpolators.py:72-130)
+
+    def compress(self, source_x, source_f, verbose=False, Verbose=False):
+        """inv(Cov(source_x, source_x)) @ source_f  ->  (N,)"""
+        verbose |= Verbose
+        gp = self._fit_checked(source_x, source_f, verbose)
+        return gp.alpha.to_host().reshape(-1)
+
+    def predict(self, target_x, source_x, compressed, verbose=False, Verbose=False):
+        """mean at target_x from the compressed representation: K(target, source; kernel) @ compressed"""
+        verbose |= Verbose
+        ctx = self.context
+        stage = _Stage(ctx, verbose)
+        xs = _lib.as_f64(target_x, ndim=2)
+        x = _lib.as_f64(source_x, ndim=2)
+        assert xs.shape[1] == x.shape[1], 'conflicting number of dimensions for x1 and x2'
+        a = _lib.as_f64(compressed).reshape(-1)
+        assert len(a) == len(x), 'compressed has %d entries for %d source points' % (len(a), len(x))
+        desc, count = _lib.make_terms(_flatten(self.kernel))
+        stage.begin('constructing %d x %d target-source covariance matrix' % (len(xs), len(x)))
+        XS = _lib.DeviceMatrix.from_host(ctx, xs)
+        X = _lib.DeviceMatrix.from_host(ctx, x)
+        A = _lib.DeviceMatrix.from_host(ctx, a)
+        out = _lib.DeviceMatrix(ctx, len(xs), 1)
+        stage.end()
+        stage.begin('computing conditioned mean')
+        # fused: K* is evaluated tile by tile inside the contraction and never stored
+        _lib.check(ctx.lib.mgpi_predict_mean_dev(ctx.handle, XS.handle, X.handle, desc, count, A.handle, out.handle))
+        stage.end()
+        return out.to_host().reshape(-1)
+
+    #--- condition (interpolators.py:136-204)
+
+    def condition(self, target_x, source_x, source_f, verbose=False, Verbose=False):
+        """mean (M,) and covariance (M, M) of the process at target_x given source_f = f(source_x);
+        zero-mean prior, Rasmussen & Williams eq 2.19"""
+        verbose |= Verbose
+        gp = self._fit_checked(source_x, source_f, verbose)
+        stage = _Stage(self.context, verbose)
+        XS = gp._targets(target_x)
+        stage.begin('computing conditioned mean')
+        mean = gp.mean_dev(XS)
+        stage.end()
+        stage.begin('computing conditioned covariance')
+        cov = gp.cov_dev(XS)
+        stage.end()
+        return mean.to_host().reshape(-1), cov.to_host()
+
+    def condition_diag(self, target_x, source_x, source_f, verbose=False, m_slab=0):
+        """additive: mean (M,) and pointwise variance (M,) = diag of condition()'s covariance, without
+        ever forming the M x M matrix"""
+        gp = self._fit_checked(source_x, source_f, verbose)
+        stage = _Stage(self.context, verbose)
+        XS = gp._targets(target_x)
+        stage.begin('computing conditioned mean')
+        mean = gp.mean_dev(XS)
+        stage.end()
+        stage.begin('computing conditioned variance')
+        var = gp.var_dev(XS, m_slab=m_slab)
+        stage.end()
+        return mean.to_host().reshape(-1), var.to_host().reshape(-1)
+
+    #--- pairwise covariance matrix (interpolators.py:208-300)
+
+    @staticmethod
+    def _x2cov(x1, x2, kernel, verbose=False):
+        """K[i, j] = kernel.cov(x1[i], x2[j])  ->  (n1, n2)"""
+        a = _lib.as_f64(x1, ndim=2)
+        b = _lib.as_f64(x2, ndim=2)
+        assert b.shape[1] == a.shape[1], 'conflicting number of dimensions for x1 and x2'
+        ctx = _lib.default_context()
+        desc, count = _lib.make_terms(kernel.terms())
+        if verbose:
+            print('computing covariance matrix')
+            t0 = time.time()
+        out = np.empty((len(a), len(b)), dtype=np.float64)
+        _lib.check(ctx.lib.mgpi_cov_matrix(ctx.handle, a.ctypes.data, len(a), b.ctypes.data, len(b), a.shape[1],
+                                           desc, count, out.ctypes.data))
+        if verbose:
+            print('    time : %.6f sec' % (time.time() - t0))
+        return out
+
+    #--- marginal likelihood (interpolators.py:331-343)
+
+    def loglikelihood(self, source_x, source_f, verbose=False):
+        """log marginal likelihood of source_f = f(source_x) under the zero-mean process"""
+        try:
+            gp = self.fit(source_x, source_f, verbose=verbose)
+        except _lib.NotPositiveDefinite:
+            raise AssertionError('covariance is not positive definite!')       # interpolators.py:340
+        f = _lib.as_f64(source_f).reshape(-1)
+        alpha = gp.alpha.to_host().reshape(-1)
+        return -0.5 * (f @ alpha) - 0.5 * gp.logdet - 0.5 * len(f) * np.log(2 * np.pi)

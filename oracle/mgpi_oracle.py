@@ -1,0 +1,167 @@
+"""CPU oracle for the mgpi dense-GP hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a numpy restatement of the reference algorithm
+(reedessick/muses-gaussian-process-interpolator @ 2024_08_07).  It is the
+*checker* for the HIP path: only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import it.  Nothing under the product
+package (``muses-gaussian-process-interpolator_amd/``) imports or calls it, and
+the product has no CPU fallback.
+
+Parity status: PINNED.  ``tests/golden/make_fixtures.py`` imports the real
+reference in the build container and stores its outputs as ``tests/golden/*.npz``;
+``tests/test_oracle_vs_golden.py`` checks every function below against them.
+(The reference's own test scripts hold no numeric fixtures - SURVEY.md section 4.)
+
+Each function cites the reference file:line whose arithmetic it restates.  The
+arithmetic is kept operation-for-operation (same association order, LU inverse
+via ``np.linalg.inv`` rather than Cholesky, exact-equality white noise, no
+factor 1/2 in the squared exponential) so that it reproduces the reference's
+rounding behaviour, not just its mathematics.
+"""
+
+import numpy as np
+
+# kernel term type codes: the same integers as include/mgpi_hip.h
+TERM_SE = 0
+TERM_WHITE = 1
+
+#-------------------------------------------------
+# kernel terms: a kernel is a list of (type, sigma, lengths) tuples that are summed
+# (mgpi/kernels.py:287-293 CombinedKernel.cov sums the member covariances in order)
+
+
+def term_se(sigma, *lengths):
+    return (TERM_SE, float(sigma), np.asarray(lengths, dtype=float))
+
+
+def term_white(sigma):
+    return (TERM_WHITE, float(sigma), np.zeros(0, dtype=float))
+
+
+def paired_cov(terms, x1, x2):
+    """row-paired covariance, x1 and x2 both (P, D) -> (P,)
+
+    SE:    mgpi/kernels.py:180-185   sigma**2 * exp(-sum((x1-x2)**2/lengths**2, axis=1))   (no 1/2)
+    white: mgpi/kernels.py:128-131   sigma**2 * all(x1==x2, axis=1)
+    sum:   mgpi/kernels.py:287-293   ans = 0.0; ans += term   (left to right)
+    """
+    x1 = np.asarray(x1, dtype=float)
+    x2 = np.asarray(x2, dtype=float)
+    total = 0.0
+    for kind, sigma, lengths in terms:
+        if kind == TERM_SE:
+            total = total + sigma**2 * np.exp(-np.sum((x1 - x2)**2 / lengths**2, axis=1))
+        elif kind == TERM_WHITE:
+            total = total + sigma**2 * np.all(x1 == x2, axis=1)
+        else:
+            raise ValueError('unknown term type %r' % (kind,))
+    return total
+
+
+def x2cov(terms, x1, x2):
+    """pairwise matrix K[i,j] = cov(x1[i], x2[j]); (n1,D),(n2,D) -> (n1,n2) row-major
+
+    mgpi/interpolators.py:208-300: materialise the n1*n2 row pairs (x1 rows each repeated n2
+    times, x2 tiled n1 times), evaluate the paired covariance, reshape.  The materialisation is
+    kept (np.repeat / np.tile) because it is what the reference spends its time on
+     and so belongs in the timed CPU baseline.
+    """
+    x1 = np.asarray(x1, dtype=float)
+    x2 = np.asarray(x2, dtype=float)
+    n1, n2 = len(x1), len(x2)
+    assert x1.shape[1] == x2.shape[1], 'conflicting number of dimensions for x1 and x2'
+    big1 = np.repeat(x1, n2, axis=0)      # interpolators.py:247-249
+    big2 = np.tile(x2, (n1, 1))           # interpolators.py:280
+    return paired_cov(terms, big1, big2).reshape((n1, n2))   # interpolators.py:293-294
+
+
+def x2cov_chunked(terms, x1, x2, rows=256):
+    """same values as x2cov, built ``rows`` rows of x1 at a time (memory-bounded variant for
+    N >= 16384 where the reference's temporaries no longer fit)"""
+    x1 = np.asarray(x1, dtype=float)
+    x2 = np.asarray(x2, dtype=float)
+    out = np.empty((len(x1), len(x2)), dtype=float)
+    for lo in range(0, len(x1), rows):
+        out[lo:lo + rows] = x2cov(terms, x1[lo:lo + rows], x2)
+    return out
+
+#-------------------------------------------------
+# Interpolator methods
+
+
+def compress(kernel, nugget, source_x, source_f):
+    """alpha = inv(K(x,x; kernel+nugget)) @ f        mgpi/interpolators.py:72-105"""
+    terms = list(kernel) + (list(nugget) if nugget else [])   # kernel+nugget, kernels.py:54-59
+    cov_src_src = x2cov(terms, source_x, source_x)            # :81-84
+    return np.linalg.inv(cov_src_src) @ np.asarray(source_f, dtype=float)   # :92, :100
+
+
+def predict(kernel, target_x, source_x, compressed):
+    """mean = K(x*,x; kernel) @ alpha  (kernel WITHOUT nugget)   mgpi/interpolators.py:109-130"""
+    return x2cov(list(kernel), target_x, source_x) @ compressed            # :117, :125
+
+
+def condition(kernel, nugget, target_x, source_x, source_f):
+    """(mean, cov) of the conditioned process   mgpi/interpolators.py:136-204 (R&W eq 2.19)
+
+    K**, K* use ``kernel``; K uses ``kernel+nugget`` (:148,:157,:166-169); LU inverse (:179);
+    left-associated products (:189, :199).
+    """
+    kterms = list(kernel)
+    sterms = kterms + (list(nugget) if nugget else [])
+    cov_tar_tar = x2cov(kterms, target_x, target_x)
+    cov_tar_src = x2cov(kterms, target_x, source_x)
+    cov_src_src = x2cov(sterms, source_x, source_x)
+    inv_cov_src_src = np.linalg.inv(cov_src_src)
+    mean = cov_tar_src @ inv_cov_src_src @ np.asarray(source_f, dtype=float)
+    cov = cov_tar_tar - cov_tar_src @ inv_cov_src_src @ np.transpose(cov_tar_src)
+    return mean, cov
+
+
+def loglikelihood(kernel, nugget, source_x, source_f):
+    """-f K^-1 f/2 - logdet K/2 - N log(2 pi)/2     mgpi/interpolators.py:331-343"""
+    terms = list(kernel) + (list(nugget) if nugget else [])
+    cov_src_src = x2cov(terms, source_x, source_x)
+    s, logdet = np.linalg.slogdet(cov_src_src)                # :339
+    assert s > 0, 'covariance is not positive definite!'      # :340
+    f = np.asarray(source_f, dtype=float)
+    return -0.5 * f @ np.linalg.inv(cov_src_src) @ f - 0.5 * logdet - 0.5 * len(f) * np.log(2 * np.pi)
+
+
+def rvs_from_conditioned(mean, cov, size=1, rng=None):
+    """mean + MVN(0, cov/outer(s,s))*s with s = sqrt(diag cov)   mgpi/interpolators.py:314-324
+    (the reference's own call at :310 raises TypeError - SURVEY.md section 0 - so no golden output
+    exists for this function: parity unpinned, statistical tests only)"""
+    rng = np.random.default_rng() if rng is None else rng
+    scales = np.diag(cov)**0.5
+    zeros = np.zeros_like(mean, dtype=float)
+    return mean + rng.multivariate_normal(zeros, cov / np.outer(scales, scales), size=size) * scales
+
+#-------------------------------------------------
+# large-N helpers (used where the LU-inverse statement above cannot run: N >= 16384)
+
+
+def cholesky_lower(K):
+    """LAPACK dpotrf via numpy; the mathematical restatement north_star assigns to the solve
+    (SURVEY.md section 0 row 3).  Only used for residual / tile-level checks."""
+    return np.linalg.cholesky(K)
+
+
+def solve_cholesky(L, b):
+    from scipy.linalg import solve_triangular
+    y = solve_triangular(L, b, lower=True)
+    return solve_triangular(L, y, lower=True, trans='T')
+
+
+def diag_variance_cholesky(kernel, L, target_x, source_x, chunk=1024):
+    """var_i = K**_ii - || L^-1 K*_i^T ||^2 : the diagonal of interpolators.py:199"""
+    from scipy.linalg import solve_triangular
+    kterms = list(kernel)
+    target_x = np.asarray(target_x, dtype=float)
+    out = np.empty(len(target_x))
+    for lo in range(0, len(target_x), chunk):
+        t = target_x[lo:lo + chunk]
+        ks = x2cov_chunked(kterms, t, source_x)
+        v = solve_triangular(L, ks.T, lower=True)
+        out[lo:lo + chunk] = paired_cov(kterms, t, t) - np.sum(v * v, axis=0)
+    return out

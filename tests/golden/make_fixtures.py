@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (read-only at /root/reference).
+
+Run in the build container only:   python3 tests/golden/make_fixtures.py
+The reference cannot travel to the GPU box, so its outputs are committed as small .npz
+files next to this script.  Each file holds inputs (x, f, xs, kernel/nugget term spec) and
+the reference's outputs (K, alpha, predict mean, condition mean/cov or diag, loglikelihood).
+
+Term spec encoding (shared with oracle/mgpi_oracle.py and include/mgpi_hip.h):
+  *_types  int array   0 = SquaredExponentialKernel, 1 = WhiteNoiseKernel
+  *_sigmas float array
+  *_lengths (nterms, D) float array (unused rows zero)
+Scenarios follow SURVEY.md section 8c.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+REFERENCE = os.environ.get('MGPI_REFERENCE', '/root/reference')
+sys.path.insert(0, REFERENCE)
+import mgpi  # noqa: E402  (the unmodified reference)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+SE, WHITE = 0, 1
+
+
+def build(terms):
+    """terms: list of ('se', sigma, lengths) / ('white', sigma) -> reference kernel object"""
+    if not terms:
+        return None
+    objs = []
+    for t in terms:
+        if t[0] == 'se':
+            objs.append(mgpi.SquaredExponentialKernel(t[1], *t[2]))
+        else:
+            objs.append(mgpi.WhiteNoiseKernel(t[1]))
+    return objs[0] if len(objs) == 1 else mgpi.CombinedKernel(*objs)
+
+
+def encode(terms, ndim, prefix):
+    types = np.array([SE if t[0] == 'se' else WHITE for t in terms], dtype=np.int64)
+    sigmas = np.array([t[1] for t in terms], dtype=float)
+    lengths = np.zeros((len(terms), ndim))
+    for i, t in enumerate(terms):
+        if t[0] == 'se':
+            lengths[i] = t[2]
+    return {prefix + '_types': types, prefix + '_sigmas': sigmas, prefix + '_lengths': lengths}
+
+
+def run(name, x, f, xs, kernel, nugget, full_cov=True, store_K=True):
+    t0 = time.time()
+    x = np.ascontiguousarray(x, dtype=float)
+    xs = np.ascontiguousarray(xs, dtype=float)
+    f = np.ascontiguousarray(f, dtype=float)
+    ndim = x.shape[1]
+    kobj, nobj = build(kernel), build(nugget)
+    interp = mgpi.Interpolator(kobj, nugget=nobj)
+
+    out = dict(x=x, f=f, xs=xs)
+    out.update(encode(kernel, ndim, 'kernel'))
+    out.update(encode(nugget, ndim, 'nugget'))
+
+    both = kobj if nobj is None else kobj + nobj
+    K = mgpi.Interpolator._x2cov(x, x, both)
+    Ks = mgpi.Interpolator._x2cov(xs, x, kobj)
+    if store_K:
+        out['K'] = K
+        out['Ks'] = Ks
+    out['K_checksum'] = np.array([K.sum(), np.abs(K).sum(), np.trace(K)])
+    out['cond_K'] = np.array(np.linalg.cond(K))
+
+    try:
+        alpha = interp.compress(x, f)
+    except np.linalg.LinAlgError:
+        # duplicated source rows make K exactly singular under the reference's exact-equality
+        # white noise (kernels.py:131): np.linalg.inv raises.  Only K / Ks are golden then.
+        out['singular'] = np.array(True)
+        alpha = None
+    if alpha is not None:
+        out['singular'] = np.array(False)
+        out['alpha'] = alpha
+        out['predict_mean'] = interp.predict(xs, x, alpha)
+
+        mean, cov = interp.condition(xs, x, f)
+        out['cond_mean'] = mean
+        if full_cov:
+            out['cond_cov'] = cov
+        out['cond_var'] = np.diag(cov).copy()
+        out['loglike'] = np.array(interp.loglikelihood(x, f))
+
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('%-28s N=%-5d M=%-5d D=%d cond(K)=%.2e  %.1fs  %.0f kB' %
+          (name, len(x), len(xs), ndim, out['cond_K'], time.time() - t0, os.path.getsize(path) / 1e3))
+
+
+def smooth(x):
+    """a smooth scalar field on [0,1]^D-ish inputs"""
+    x = np.asarray(x, dtype=float)
+    w = np.arange(1, x.shape[1] + 1)
+    return np.sin(2.0 * x @ w / len(w)) + 0.5 * np.cos(3.0 * x[:, 0]) * np.prod(np.cos(x[:, 1:]), axis=1)
+
+
+def main():
+    # (1) toys: N in {1,2,3,17,64}, D in {1,2,3,4}; duplicated source rows; targets on sources
+    rng = np.random.default_rng(1)
+    for n, d in [(1, 1), (2, 2), (3, 3), (17, 4), (64, 2), (64, 3)]:
+        x = rng.random((n, d))
+        f = smooth(x)
+        xs = np.vstack([rng.random((5, d)), x[:min(n, 3)]])          # last rows coincide with sources
+        ell = tuple(0.3 + 0.1 * i for i in range(d))
+        # white noise INSIDE the kernel (how every reference test script uses it)
+        run('toy_n%d_d%d_whitein' % (n, d), x, f, xs,
+            [('se', 1.3, ell), ('white', 1e-2)], [])
+        # white noise as nugget
+        run('toy_n%d_d%d_nugget' % (n, d), x, f, xs,
+            [('se', 1.3, ell)], [('white', 1e-2)])
+
+    # duplicated source rows: the exact-equality nugget puts sigma_n^2 OFF the diagonal too
+    x = rng.random((12, 2))
+    x[7] = x[2]
+    x[11] = x[2]
+    f = smooth(x)
+    f[7] += 1e-3
+    xs = np.vstack([rng.random((4, 2)), x[2:3]])
+    run('toy_duplicates', x, f, xs, [('se', 0.9, (0.35, 0.25))], [('white', 0.05)])
+
+    # two SE terms + two white terms (CombinedKernel flattening, kernels.py:54-59)
+    x = rng.random((40, 3))
+    run('toy_multiterm', x, smooth(x), rng.random((9, 3)),
+        [('se', 1.0, (0.3, 0.4, 0.5)), ('se', 0.2, (0.05, 0.07, 0.06)), ('white', 3e-3)],
+        [('white', 1e-2)])
+
+    # no white noise at all, well separated points (K well conditioned on its own)
+    x = rng.random((30, 2)) * 4.0
+    run('toy_nonugget', x, smooth(x), rng.random((6, 2)) * 4.0, [('se', 1.0, (0.5, 0.5))], [])
+
+    # (2) uiuc-test style: 2-D grid, checkerboard split, sigma = 1.5 std f, ell = 2*spacing,
+    #     white sigma/1000 inside the CombinedKernel (test/uiuc/uiuc-test:114-189); mean subtracted (:203)
+    g0 = np.linspace(0.0, 150.0, 24)
+    g1 = np.linspace(30.0, 100.0, 24)
+    G0, G1 = np.meshgrid(g0, g1, indexing='ij')
+    full = np.transpose([G0.ravel(), G1.ravel()])
+    ff = 0.3 + 0.1 * np.tanh((full[:, 1] - 60.0) / 15.0) + 0.02 * np.sin(full[:, 0] / 40.0)
+    parity = (np.add.outer(np.arange(24), np.arange(24)) % 2).ravel().astype(bool)
+    x, f, xs = full[parity], ff[parity], full[~parity][::3]
+    f = f - np.mean(f)
+    sig = 1.5 * np.std(f)
+    ell = (2 * (g0[1] - g0[0]), 2 * (g1[1] - g1[0]))
+    run('uiuc_checkerboard_whitein', x, f, xs, [('se', sig, ell), ('white', sig / 1000.)], [])
+    run('uiuc_checkerboard_nugget', x, f, xs, [('se', sig, ell)], [('white', sig / 1000.)])
+
+    # (3) sc-eos-test style: 3-D, sigma = 2 std f, ell = 2*spacing, nugget sigma/100
+    #     (test/stellarcollapse-eos/sc-eos-test:132-148), regular target grid (:172-176)
+    a = [np.linspace(0.05, 0.5, 6), np.linspace(4.0, 14.0, 9), np.linspace(17.0, 22.0, 8)]
+    A = np.meshgrid(*a, indexing='ij')
+    x = np.transpose([_.ravel() for _ in A])
+    f = 0.6 * (x[:, 2] - 17.0) - 0.05 * (x[:, 1] - 9.0) + 0.5 * np.sin(4 * x[:, 0])
+    f = f - np.mean(f)
+    sig = 2 * np.std(f)
+    ell = tuple(2 * (_[1] - _[0]) for _ in a)
+    b = [np.linspace(_[0], _[-1], 5) for _ in a]
+    B = np.meshgrid(*b, indexing='ij')
+    xs = np.transpose([_.ravel() for _ in B])
+    run('sceos_3d', x, f, xs, [('se', sig, ell)], [('white', sig / 100.)])
+
+    # (4)/(5) C1: etc/example-interpolator.ini values (SE sigma=0.1, ell=(10,20); nugget 1e-4; the
+    #     Matern term dropped) on a synthetic (muB, T) table: N=512, D=2
+    rng = np.random.default_rng(0)
+    g0 = np.linspace(0.0, 150.0, 32)
+    g1 = np.linspace(30.0, 100.0, 32)
+    G0, G1 = np.meshgrid(g0, g1, indexing='ij')
+    full = np.transpose([G0.ravel(), G1.ravel()])
+    ff = 0.05 * np.tanh((full[:, 1] - 60.0) / 20.0) + 0.01 * np.sin(full[:, 0] / 30.0) + 1e-4 * rng.standard_normal(len(full))
+    x, f = full[::2], ff[::2]                     # io.py:113-120 row-stride downsample = 2 -> 512 rows
+    xs = np.transpose([rng.uniform(0, 150, 256), rng.uniform(30, 100, 256)])
+    run('c1_n512_d2', x, f, xs, [('se', 0.1, (10., 20.))], [('white', 1e-4)])
+
+    # (6) larger direct-oracle cases: full K not stored
+    for n, seed in [(2048, 6), (4096, 7)]:
+        rng = np.random.default_rng(seed)
+        side = np.array([16, 16, n // 256])
+        axes = [(np.arange(s) + 0.5) / s for s in side]
+        A = np.meshgrid(*axes, indexing='ij')
+        x = np.transpose([_.ravel() for _ in A])
+        x = x + rng.uniform(-0.1, 0.1, x.shape) / side
+        f = np.sin(3 * x[:, 0]) * np.cos(2 * x[:, 1]) + 0.5 * np.sin(4 * x[:, 2])
+        xs = rng.random((256, 3))
+        ell = tuple(2.0 / side)
+        run('grid_n%d_d3' % n, x, f, xs, [('se', 1.0, ell)], [('white', 1e-2)],
+            full_cov=False, store_K=False)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,165 @@
+"""Tile-level checks of the HIP building blocks through the C-ABI (ctypes): the fp64 MFMA gemm (layout bugs
+show up as exact-integer mismatches), the blocked Cholesky against LAPACK, the triangular solves, and the
+size-independent properties at BASELINE.json's full single-GPU sizes (C2 N=8192, C3 N=32768)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import mgpi_amd as mgpi
+from mgpi_amd import _lib
+from conftest import relmax
+from oracle import mgpi_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    return mgpi.default_context()
+
+
+def dev(ctx, a, wide=True):
+    return _lib.DeviceMatrix.from_host(ctx, a, wide=wide)
+
+
+@pytest.mark.parametrize('m,n,k', [(128, 128, 16), (256, 128, 64), (128, 384, 512), (640, 640, 128)])
+def test_gemm_nt_exact_integers(ctx, m, n, k):
+    """C -= A B^T with small integers is exact in fp64: any fragment/lane mapping error shows as a mismatch.
+    A and B are asymmetric and C is not symmetric, so a transposed write-back cannot hide."""
+    rng = np.random.default_rng(m + n + k)
+    A = rng.integers(-8, 9, (m, k)).astype(float)
+    B = rng.integers(-8, 9, (n, k)).astype(float)
+    C = rng.integers(-100, 100, (m, n)).astype(float)
+    dC = dev(ctx, C)
+    _lib.check(ctx.lib.mgpi_gemm_nt_dev(ctx.handle, dev(ctx, A).handle, dev(ctx, B).handle, dC.handle, 0))
+    assert np.array_equal(dC.to_host(), C - A @ B.T)
+
+
+def test_gemm_lower_only_touches_lower_tiles(ctx):
+    rng = np.random.default_rng(0)
+    n, k = 512, 64
+    A = rng.integers(-4, 5, (n, k)).astype(float)
+    C = rng.integers(-50, 50, (n, n)).astype(float)
+    dC = dev(ctx, C)
+    dA = dev(ctx, A)
+    _lib.check(ctx.lib.mgpi_gemm_nt_dev(ctx.handle, dA.handle, dA.handle, dC.handle, 1))
+    got = dC.to_host()
+    full = C - A @ A.T
+    ti = np.arange(n)[:, None] // 128
+    tj = np.arange(n)[None, :] // 128
+    assert np.array_equal(got[tj <= ti], full[tj <= ti])        # tiles on/below the diagonal updated
+    assert np.array_equal(got[tj > ti], C[tj > ti])             # strictly-upper tiles untouched
+
+
+@pytest.mark.parametrize('n', [1, 2, 63, 64, 65, 128, 200, 513, 1111])
+def test_potrf_against_lapack(ctx, n):
+    rng = np.random.default_rng(n)
+    x = rng.random((n, 2))
+    terms = [oracle.term_se(1.0, 0.2, 0.3), oracle.term_white(0.05)]
+    K = oracle.x2cov_chunked(terms, x, x)
+    dK = dev(ctx, K)
+    logdet = ctypes.c_double(0.0)
+    _lib.check(ctx.lib.mgpi_potrf_dev(ctx.handle, dK.handle, ctypes.byref(logdet)))
+    L = np.tril(dK.to_host())
+    ref = np.linalg.cholesky(K)
+    assert relmax(L, ref) < 1e-11
+    assert np.max(np.abs(L @ L.T - K)) / np.max(np.abs(K)) < 1e-14
+    assert abs(logdet.value - np.linalg.slogdet(K)[1]) < 1e-10 * max(1.0, abs(logdet.value))
+
+
+def test_potrf_reports_first_bad_pivot(ctx):
+    K = np.eye(300)
+    K[150, 150] = -1.0
+    dK = dev(ctx, K)
+    with pytest.raises(mgpi.NotPositiveDefinite) as err:
+        _lib.check(ctx.lib.mgpi_potrf_dev(ctx.handle, dK.handle, None))
+    assert err.value.pivot == 151
+    assert 'covariance is not positive definite!' in str(err.value)
+    b = dev(ctx, np.ones(300), wide=False)
+    with pytest.raises(mgpi.MgpiError):          # solving with an unfactored matrix is a state error
+        _lib.check(ctx.lib.mgpi_potrs_dev(ctx.handle, dK.handle, b.handle))
+
+
+@pytest.mark.parametrize('n,nrhs', [(100, 1), (700, 1), (700, 5), (1300, 130)])
+def test_potrs_and_trsm(ctx, n, nrhs):
+    rng = np.random.default_rng(n + nrhs)
+    x = rng.random((n, 3))
+    K = oracle.x2cov_chunked([oracle.term_se(1.0, 0.2, 0.2, 0.2), oracle.term_white(0.1)], x, x)
+    B = rng.standard_normal((n, nrhs))
+    dK = dev(ctx, K)
+    _lib.check(ctx.lib.mgpi_potrf_dev(ctx.handle, dK.handle, None))
+    out = np.empty_like(B)
+    _lib.check(ctx.lib.mgpi_potrs(ctx.handle, dK.handle, B.ctypes.data, n, nrhs, out.ctypes.data))
+    ref = np.linalg.solve(K, B)
+    assert relmax(out, ref) < 1e-10
+    if nrhs > 1:
+        L = np.linalg.cholesky(K)
+        from scipy.linalg import solve_triangular
+        for trans in (0, 1):
+            dB = dev(ctx, B)
+            _lib.check(ctx.lib.mgpi_trsm_dev(ctx.handle, dK.handle, dB.handle, trans))
+            assert relmax(dB.to_host(), solve_triangular(L, B, lower=True, trans=trans)) < 1e-10
+
+
+def test_c_abi_host_entry_points(ctx):
+    """the host-pointer entry points a ctypes binding at the reference's call sites would use"""
+    rng = np.random.default_rng(21)
+    x1, x2 = rng.random((70, 3)), rng.random((45, 3))
+    desc, n = _lib.make_terms([(0, 1.2, (0.3, 0.4, 0.5)), (1, 0.1, ())])
+    out = np.empty((70, 45))
+    _lib.check(ctx.lib.mgpi_cov_matrix(ctx.handle, x1.ctypes.data, 70, x2.ctypes.data, 45, 3, desc, n, out.ctypes.data))
+    ref = oracle.x2cov([oracle.term_se(1.2, 0.3, 0.4, 0.5), oracle.term_white(0.1)], x1, x2)
+    np.testing.assert_allclose(out, ref, rtol=5e-14)
+    sym = np.empty((70, 70))
+    _lib.check(ctx.lib.mgpi_cov_matrix(ctx.handle, x1.ctypes.data, 70, None, 0, 3, desc, n, sym.ctypes.data))
+    np.testing.assert_allclose(sym, oracle.x2cov([oracle.term_se(1.2, 0.3, 0.4, 0.5), oracle.term_white(0.1)], x1, x1), rtol=5e-14)
+    # bad arguments come back as negative statuses with a message, never a crash
+    assert ctx.lib.mgpi_cov_matrix(ctx.handle, x1.ctypes.data, 70, x2.ctypes.data, 45, 99, desc, n, out.ctypes.data) < 0
+    assert 'd=99' in _lib.last_error()
+
+
+def _c_config(n_side, d, seed):
+    """SURVEY.md section 8d recipe: jittered grid in [0,1]^d, f = sin/cos product, SE sigma=1, ell=2*spacing,
+    white sigma_n=1e-2"""
+    rng = np.random.default_rng(seed)
+    axes = [(np.arange(s) + 0.5) / s for s in n_side]
+    x = np.transpose([a.ravel() for a in np.meshgrid(*axes, indexing='ij')])
+    x = x + rng.uniform(-0.1, 0.1, x.shape) / np.array(n_side)
+    f = np.sin(3 * x[:, 0]) * np.cos(2 * x[:, 1]) + 0.5 * np.sin(4 * x[:, 2])
+    ell = tuple(2.0 / np.array(n_side))
+    return x, f, ell
+
+
+@pytest.mark.parametrize('n_side,seed', [((32, 16, 16), 2), ((32, 32, 32), 3)])
+def test_full_size_properties(n_side, seed):
+    """C2 (N=8192) and C3 (N=32768): the reference cannot run C3 at all, so parity at
+    full size is through size-independent properties:
+      residual   || (K+nugget) alpha - f ||_inf / ||f||_inf        (K alpha via the fused contraction)
+      variance   0 <= var <= prior, and var at source points ~ sigma_n^2 scale
+      linearity  alpha(f1 + 2 f2) == alpha(f1) + 2 alpha(f2)
+      logdet     identical when the sources are permuted"""
+    x, f, ell = _c_config(n_side, 3, seed)
+    n = len(x)
+    rng = np.random.default_rng(seed)
+    k = mgpi.SquaredExponentialKernel(1.0, *ell)
+    nug = mgpi.WhiteNoiseKernel(1e-2)
+    it = mgpi.Interpolator(k, nugget=nug)
+    gp = it.fit(x, f)
+    alpha = gp.alpha.to_host().reshape(-1)
+    # K alpha: predict with kernel+nugget at the sources themselves
+    Kalpha = mgpi.Interpolator(k + nug).predict(x, x, alpha)
+    assert np.max(np.abs(Kalpha - f)) / np.max(np.abs(f)) < 1e-10
+    xs = rng.random((512, 3))
+    xs[:8] = x[:8]
+    var = gp.variance(xs)
+    assert np.all(var > -1e-9) and np.all(var <= 1.0 + 1e-12)
+    assert np.all(var[:8] < 1.1e-4 + 1e-9)            # at a source the variance is below the noise variance
+    f2 = np.cos(5 * x[:, 1])
+    a2 = it.fit(x, f2).alpha.to_host().reshape(-1)
+    a12 = it.fit(x, f + 2 * f2).alpha.to_host().reshape(-1)
+    assert relmax(a12, alpha + 2 * a2) < 1e-9
+    perm = rng.permutation(n)
+    gp_p = it.fit(x[perm], f[perm])
+    assert abs(gp_p.logdet - gp.logdet) < 1e-9 * abs(gp.logdet)
+    assert relmax(gp_p.alpha.to_host().reshape(-1), alpha[perm]) < 1e-8

@@ -1,0 +1,216 @@
+"""Parity of the HIP path (through the C-ABI, via the Python host) against the golden vectors of the real
+reference and against the oracle on seeded inputs.  Needs an MI355X: run with -m gpu.
+
+Stated tolerances (fp64; SURVEY.md section 8c, conftest.mean_tol / var_tol):
+  K entries           rtol 5e-13 everywhere (exp argument r carries ~2 ulp*r), 5e-14 where K > 1e-6 max K
+  mean / predict      max-norm-relative <= 1e-10 for cond(K) <= 1e7, 4e-17*cond beyond
+  variance / cov      <= 1e-8 * prior variance for cond(K) <= 1e7
+  alpha               <= 100 * cond * eps (the reference's LU inverse is itself only this reproducible)
+  loglikelihood       rtol 1e-10 (cond-scaled like the mean)
+"""
+import numpy as np
+import pytest
+
+import mgpi_amd as mgpi
+from conftest import golden_names, load_golden, mean_tol, oracle_terms, prior_var, product_kernel, relmax, var_tol
+from oracle import mgpi_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+NAMES = golden_names()
+EPS = 2.220446049250313e-16
+
+
+def assert_K_close(K, ref):
+    assert K.shape == ref.shape
+    np.testing.assert_allclose(K, ref, rtol=5e-13, atol=0)
+    big = ref > 1e-6 * np.max(ref)
+    np.testing.assert_allclose(K[big], ref[big], rtol=5e-14, atol=0)
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_golden(name):
+    g = load_golden(name)
+    kernel, nugget = product_kernel(g, 'kernel'), product_kernel(g, 'nugget')
+    x, f, xs = g['x'], g['f'], g['xs']
+    interp = mgpi.Interpolator(kernel, nugget=nugget)
+    both = kernel if nugget is None else kernel + nugget
+
+    if 'K' in g:
+        assert_K_close(mgpi.Interpolator._x2cov(x, x, both), g['K'])
+        assert_K_close(mgpi.Interpolator._x2cov(xs, x, kernel), g['Ks'])
+    else:
+        K = mgpi.Interpolator._x2cov(x, x, both)
+        np.testing.assert_allclose([K.sum(), np.abs(K).sum(), np.trace(K)], g['K_checksum'], rtol=1e-13)
+
+    if bool(g['singular']):
+        # duplicated rows under the exact-equality white noise: K is exactly singular and the reference's
+        # inv raises LinAlgError; the device Cholesky reports the vanishing pivot
+        with pytest.raises(np.linalg.LinAlgError):
+            interp.compress(x, f)
+        with pytest.raises(AssertionError):
+            interp.loglikelihood(x, f)
+        return
+
+    cond = float(g['cond_K'])
+    alpha = interp.compress(x, f)
+    assert alpha.shape == (len(x),) and alpha.flags['C_CONTIGUOUS']
+    assert relmax(alpha, g['alpha']) < max(1e-12, 100 * cond * EPS)
+
+    pred = interp.predict(xs, x, alpha)
+    assert pred.shape == (len(xs),)
+    assert relmax(pred, g['predict_mean']) < mean_tol(cond)
+    # the reference's own compressed vector through our predict: isolates the fused K* contraction
+    assert relmax(interp.predict(xs, x, g['alpha']), g['predict_mean']) < 1e-12
+
+    mean, cov = interp.condition(xs, x, f)
+    assert mean.shape == (len(xs),) and cov.shape == (len(xs), len(xs))
+    assert relmax(mean, g['cond_mean']) < mean_tol(cond)
+    pv = prior_var(g)
+    assert np.max(np.abs(np.diag(cov) - g['cond_var'])) / pv < var_tol(cond)
+    if 'cond_cov' in g:
+        assert np.max(np.abs(cov - g['cond_cov'])) / pv < var_tol(cond)
+
+    mean2, var = interp.condition_diag(xs, x, f)
+    assert relmax(mean2, g['cond_mean']) < mean_tol(cond)
+    assert np.max(np.abs(var - g['cond_var'])) / pv < var_tol(cond)
+
+    ll = interp.loglikelihood(x, f)
+    assert abs(ll - float(g['loglike'])) <= mean_tol(cond) * abs(float(g['loglike']))
+
+
+@pytest.mark.parametrize('d', [1, 2, 3, 4, 5, 7, 16])
+def test_paired_cov_matches_oracle(d):
+    """Kernel.cov keeps the reference's row-paired semantics (kernels.py:89-93)"""
+    rng = np.random.default_rng(d)
+    p = 1000
+    x1 = rng.random((p, d))
+    x2 = rng.random((p, d))
+    x2[::7] = x1[::7]                       # exact coincidences -> white noise fires
+    x2[3, 0] = np.nextafter(x1[3, 0], 2.0)  # one ulp apart is NOT equal
+    ell = tuple(0.2 + 0.05 * k for k in range(d))
+    k = mgpi.SquaredExponentialKernel(1.5, *ell) + mgpi.WhiteNoiseKernel(0.3) + mgpi.SquaredExponentialKernel(0.2, *(2 * np.array(ell)))
+    terms = [oracle.term_se(1.5, *ell), oracle.term_white(0.3), oracle.term_se(0.2, *(2 * np.array(ell)))]
+    got = k.cov(x1, x2)
+    ref = oracle.paired_cov(terms, x1, x2)
+    assert got.shape == (p,)
+    np.testing.assert_allclose(got, ref, rtol=5e-14, atol=0)
+    # white noise delta is exact
+    w = mgpi.WhiteNoiseKernel(0.3).cov(x1, x2)
+    assert np.array_equal(w, oracle.paired_cov([oracle.term_white(0.3)], x1, x2))
+    assert w[0] == 0.3**2 and w[1] == 0.0 and w[3] == 0.0
+
+
+def test_se_convention_and_diagonal():
+    """no factor 1/2 (kernels.py:185); K_ii = sigma^2 (+ sigma_n^2)"""
+    se = mgpi.SquaredExponentialKernel(2.0, 0.5)
+    assert abs(se.cov([[0.0]], [[0.5]])[0] - 4.0 * np.exp(-1.0)) < 1e-15
+    K = mgpi.Interpolator._x2cov([[0.0], [0.5], [0.0]], [[0.0], [0.5], [0.0]], se + mgpi.WhiteNoiseKernel(0.1))
+    assert K[0, 0] == 4.0 + 0.1**2 and K[0, 2] == 4.0 + 0.1**2     # duplicated rows get the nugget off-diagonal
+    assert abs(K[0, 1] - 4.0 * np.exp(-1.0)) < 1e-15
+
+
+def test_closed_forms_n1_n2():
+    se = mgpi.SquaredExponentialKernel(2.0, 0.5)
+    it = mgpi.Interpolator(se, nugget=mgpi.WhiteNoiseKernel(0.1))
+    kk = 4.0 + 0.01
+    ll = it.loglikelihood([[0.3]], [1.5])
+    assert abs(ll - (-0.5 * 1.5**2 / kk - 0.5 * np.log(kk) - 0.5 * np.log(2 * np.pi))) < 1e-14
+    mean, cov = it.condition([[0.3]], [[0.3]], [1.5])
+    assert abs(mean[0] - 1.5 * 4.0 / kk) < 1e-14 and abs(cov[0, 0] - (4.0 - 16.0 / kk)) < 1e-13
+    # N = 2 against the explicit 2x2 inverse
+    x = np.array([[0.0], [0.4]])
+    f = np.array([1.0, -0.5])
+    c = 4.0 * np.exp(-(0.4 / 0.5)**2)
+    Kinv = np.array([[kk, -c], [-c, kk]]) / (kk * kk - c * c)
+    assert relmax(it.compress(x, f), Kinv @ f) < 1e-14
+
+
+def test_exact_interpolation_as_nugget_vanishes():
+    rng = np.random.default_rng(5)
+    x = rng.random((40, 2)) * 3
+    f = np.sin(x[:, 0]) + x[:, 1]
+    it = mgpi.Interpolator(mgpi.SquaredExponentialKernel(1.0, 0.4, 0.4), nugget=mgpi.WhiteNoiseKernel(1e-7))
+    mean, var = it.condition_diag(x, x, f)
+    assert relmax(mean, f) < 1e-9 and np.max(np.abs(var)) < 1e-9
+
+
+def test_predict_of_compress_equals_condition_mean():
+    g = load_golden('sceos_3d')
+    it = mgpi.Interpolator(product_kernel(g, 'kernel'), nugget=product_kernel(g, 'nugget'))
+    a = it.compress(g['x'], g['f'])
+    m1 = it.predict(g['xs'], g['x'], a)
+    m2, _ = it.condition(g['xs'], g['x'], g['f'])
+    assert relmax(m1, m2) < 1e-12
+
+
+@pytest.mark.parametrize('n,m,d,seed', [(257, 33, 2, 11), (640, 129, 3, 12), (1500, 300, 4, 13), (1100, 17, 1, 14)])
+def test_seeded_against_oracle(n, m, d, seed):
+    """ragged sizes (not multiples of any tile), against the oracle's LU-inverse statement"""
+    rng = np.random.default_rng(seed)
+    x = rng.random((n, d))
+    xs = rng.random((m, d))
+    f = np.sin(4 * x[:, 0]) + (x[:, -1] - 0.5)**2
+    ell = tuple(np.full(d, 1.5 * n**(-1.0 / d)))
+    it = mgpi.Interpolator(mgpi.SquaredExponentialKernel(1.0, *ell), nugget=mgpi.WhiteNoiseKernel(1e-2))
+    kernel, nugget = [oracle.term_se(1.0, *ell)], [oracle.term_white(1e-2)]
+    K = oracle.x2cov_chunked(kernel + nugget, x, x)
+    cond = np.linalg.cond(K)
+    ref_mean, ref_cov = oracle.condition(kernel, nugget, xs, x, f)
+    mean, cov = it.condition(xs, x, f)
+    assert relmax(mean, ref_mean) < mean_tol(cond)
+    assert np.max(np.abs(cov - ref_cov)) < var_tol(cond)
+    mean2, var = it.condition_diag(xs, x, f, m_slab=128)      # several query slabs
+    assert relmax(mean2, ref_mean) < mean_tol(cond)
+    assert np.max(np.abs(var - np.diag(ref_cov))) < var_tol(cond)
+    ll = it.loglikelihood(x, f)
+    ref_ll = oracle.loglikelihood(kernel, nugget, x, f)
+    assert abs(ll - ref_ll) < mean_tol(cond) * abs(ref_ll)
+
+
+def test_input_layouts_and_errors():
+    rng = np.random.default_rng(3)
+    cols = [rng.random(50), rng.random(50)]
+    xF = np.transpose(cols)                    # F-ordered (N, D) view, what parse_table returns (io.py:123)
+    assert not xF.flags['C_CONTIGUOUS']
+    xC = np.ascontiguousarray(xF)
+    f = rng.random(50)
+    k = mgpi.SquaredExponentialKernel(1.0, 0.3, 0.3)
+    it = mgpi.Interpolator(k, nugget=mgpi.WhiteNoiseKernel(0.1))
+    assert np.array_equal(it.compress(xF, f), it.compress(xC, f))
+    assert np.array_equal(it.compress(xC.tolist(), f.tolist()), it.compress(xC, f))
+    with pytest.raises(AssertionError):       # interpolators.py:219
+        mgpi.Interpolator._x2cov(xC, rng.random((5, 3)), k)
+    with pytest.raises(AssertionError):
+        it.predict(rng.random((5, 3)), xC, f)
+    # not positive definite: loglikelihood asserts like interpolators.py:340; compress raises LinAlgError
+    bad = mgpi.Interpolator(mgpi.SquaredExponentialKernel(1.0, 50.0, 50.0))      # nearly rank one, no nugget
+    with pytest.raises(AssertionError, match='covariance is not positive definite!'):
+        bad.loglikelihood(xC, f)
+    with pytest.raises(np.linalg.LinAlgError):
+        bad.compress(xC, f)
+
+
+def test_verbose_stage_banners(capsys):
+    rng = np.random.default_rng(4)
+    x = rng.random((20, 2))
+    it = mgpi.Interpolator(mgpi.SquaredExponentialKernel(1.0, 0.3, 0.3), nugget=mgpi.WhiteNoiseKernel(0.1))
+    it.condition(x[:5], x, rng.random(20), verbose=True)
+    out = capsys.readouterr().out
+    for phrase in ['constructing 20 x 20 source-source covariance matrix', 'inverting source-source covariance matrix',
+                   'computing conditioned mean', 'computing conditioned covariance', '    time : ']:
+        assert phrase in out
+
+
+def test_update_invalidates_nothing_stale():
+    """objects are mutable (update); every call must see the current parameters"""
+    rng = np.random.default_rng(8)
+    x = rng.random((30, 1))
+    f = rng.random(30)
+    k = mgpi.SquaredExponentialKernel(1.0, 0.2)
+    it = mgpi.Interpolator(k, nugget=mgpi.WhiteNoiseKernel(0.1))
+    a1 = it.compress(x, f)
+    it.update(sigma=2.0)
+    a2 = it.compress(x, f)
+    ref = oracle.compress([oracle.term_se(2.0, 0.2)], [oracle.term_white(0.1)], x, f)
+    assert relmax(a2, ref) < 1e-11 and relmax(a1, a2) > 1e-3

@@ -1,0 +1,149 @@
+"""CPU-side checks: the host mirror of the reference API, and that the C-ABI library loads and exports
+every symbol include/mgpi_hip.h declares.  No compute calls (there is no GPU here)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import mgpi_amd as mgpi
+from conftest import ROOT
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, 'include', 'mgpi_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(mgpi_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = mgpi._lib.load_library()
+    declared = header_functions()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), 'libmgpi_hip.so does not export %s' % name
+    # and the ctypes prototype table covers exactly the header
+    assert sorted(mgpi._lib.EXPORTED_SYMBOLS) == declared
+
+
+def test_kernel_desc_layout_matches_header():
+    import ctypes
+    d = mgpi._lib.KernelDesc
+    assert ctypes.sizeof(d) == 4 + 4 + 8 + 8 + 8 * 16
+    assert d.sigma.offset == 8 and d.order.offset == 16 and d.length.offset == 24
+
+
+def test_no_gpu_fails_loudly():
+    """the product has no CPU fallback: without a device the context cannot be created"""
+    if mgpi._lib.device_count() > 0:
+        pytest.skip('a GPU is present')
+    with pytest.raises(mgpi.MgpiError):
+        mgpi.Context(device=0)
+    k = mgpi.SquaredExponentialKernel(1.0, 0.5)
+    with pytest.raises(mgpi.MgpiError):
+        mgpi.Interpolator(k).compress(np.zeros((4, 1)), np.zeros(4))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'muses-gaussian-process-interpolator_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for name in files:
+            if name.endswith(('.py', '.hip', '.h')):
+                text = open(os.path.join(dirpath, name)).read()
+                assert 'mgpi_oracle' not in text and 'from oracle' not in text and 'import oracle' not in text, name
+
+
+# ---- parameter containers: behaviour of mgpi/kernels.py:24-118,191-285 -----------------------------------
+
+def test_parameter_names_and_values():
+    se = mgpi.SquaredExponentialKernel(0.1, 10, 20)
+    assert se._params == ('sigma', 'length0', 'length1')
+    assert se.num_dim == 2
+    assert se.params.dtype == float and list(se.params) == [0.1, 10.0, 20.0]
+    assert se.params_dict == {'sigma': 0.1, 'length0': 10.0, 'length1': 20.0}
+    assert se.params_array.dtype.names == ('sigma', 'length0', 'length1')
+    assert se.params_array['length1'][0] == 20.0
+    wn = mgpi.WhiteNoiseKernel(1e-4)
+    assert wn._params == ('sigma',)
+    ma = mgpi.MaternKernel(2, 0.1, 15, 10)
+    assert ma._params == ('order', 'sigma', 'length0', 'length1') and ma.num_dim == 2
+    assert str(wn) == 'WhiteNoiseKernel(sigma=1.000000e-04)'
+    with pytest.raises(AssertionError):
+        mgpi.WhiteNoiseKernel()
+    with pytest.raises(AssertionError):
+        mgpi.SquaredExponentialKernel(1.0)
+
+
+def test_update_forms():
+    se = mgpi.SquaredExponentialKernel(1.0, 2.0, 3.0)
+    se.update(4, 5, 6)
+    assert list(se.params) == [4, 5, 6]
+    se.update(sigma=7)
+    se.update({'length1': 9})
+    assert list(se.params) == [7, 5, 9]
+    with pytest.warns(UserWarning):
+        se.update(nonsense=1)
+    with pytest.raises(ValueError):
+        se.update(1, 2)
+    with pytest.raises(ValueError):
+        se.update(1, 2, 3, sigma=1)
+
+
+def test_combined_kernel_flattening_and_names():
+    a = mgpi.SquaredExponentialKernel(1.0, 0.3, 0.4)
+    b = mgpi.WhiteNoiseKernel(0.01)
+    c = mgpi.SquaredExponentialKernel(0.5, 1.0, 2.0)
+    ab = a + b
+    assert isinstance(ab, mgpi.CombinedKernel) and ab.kernels == (a, b)
+    abc = ab + c
+    assert abc.kernels == (a, b, c)                       # flat, never nested (kernels.py:54-59)
+    assert (c + ab).kernels == (c, a, b)
+    assert abc._params == ('sigma_0', 'length0_0', 'length1_0', 'sigma_1', 'sigma_2', 'length0_2', 'length1_2')
+    assert list(abc.params) == [1.0, 0.3, 0.4, 0.01, 0.5, 1.0, 2.0]
+    abc.update(sigma_1=0.02, length1_2=5.0)
+    assert b.params[0] == 0.02 and c.params[2] == 5.0    # members are shared, not copied
+    abc.update(*range(7))
+    assert list(abc.params) == list(range(7))
+    assert abc.terms() == [(0, 0.0, (1.0, 2.0)), (1, 3.0, ()), (0, 4.0, (5.0, 6.0))]
+    with pytest.raises(AssertionError):
+        mgpi.CombinedKernel(a)
+    with pytest.raises(AssertionError):
+        mgpi.CombinedKernel(a, mgpi.SquaredExponentialKernel(1.0, 1.0))
+    with pytest.raises(RuntimeError):
+        abc.update(sigma=1.0)
+    assert 'kernel 0  : SquaredExponentialKernel' in str(abc)
+
+
+def test_factory_finds_classes_by_name():
+    """how the reference's INI loader resolves `type = ...` (utils.py:20-26, io.py:408,537)"""
+    kernels = mgpi.factory(mgpi.Kernel)
+    for name in ['Kernel', 'NDKernel', 'WhiteNoiseKernel', 'MaternKernel', 'SquaredExponentialKernel', 'CombinedKernel']:
+        assert kernels[name].__name__ == name
+    assert mgpi.factory(mgpi.Interpolator)['Interpolator'] is mgpi.Interpolator
+    assert issubclass(mgpi.SquaredExponentialKernel, mgpi.MaternKernel)
+
+
+def test_interpolator_holds_kernel_and_nugget():
+    k = mgpi.SquaredExponentialKernel(1.0, 1.0)
+    it = mgpi.Interpolator(k)
+    it.update(sigma=3.0)
+    assert k.params[0] == 3.0
+    with pytest.raises(RuntimeError):
+        it.update_nugget(sigma=1.0)
+    it = mgpi.Interpolator(k, nugget=mgpi.WhiteNoiseKernel(0.1))
+    it.update_nugget(sigma=0.2)
+    assert it.nugget.params[0] == 0.2
+
+
+def test_matern_has_no_silent_cpu_path():
+    with pytest.raises(NotImplementedError):
+        mgpi.MaternKernel(2, 1.0, 1.0).terms()
+
+
+def test_make_terms_limits():
+    with pytest.raises(ValueError):
+        mgpi._lib.make_terms([])
+    with pytest.raises(ValueError):
+        mgpi._lib.make_terms([(0, 1.0, tuple(range(1, 18)))])
+    arr, n = mgpi._lib.make_terms([(0, 2.0, (1.0, 3.0)), (1, 0.5, ())])
+    assert n == 2 and arr[0].sigma == 2.0 and arr[0].length[1] == 3.0 and arr[1].type == 1
