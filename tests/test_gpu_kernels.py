@@ -31,8 +31,8 @@ def test_gemm_nt_exact_integers(ctx, m, n, k):
     A = rng.integers(-8, 9, (m, k)).astype(float)
     B = rng.integers(-8, 9, (n, k)).astype(float)
     C = rng.integers(-100, 100, (m, n)).astype(float)
-    dC = dev(ctx, C)
-    _lib.check(ctx.lib.mgpi_gemm_nt_dev(ctx.handle, dev(ctx, A).handle, dev(ctx, B).handle, dC.handle, 0))
+    dA, dB, dC = dev(ctx, A), dev(ctx, B), dev(ctx, C)      # keep the handles alive across the call
+    _lib.check(ctx.lib.mgpi_gemm_nt_dev(ctx.handle, dA.handle, dB.handle, dC.handle, 0))
     assert np.array_equal(dC.to_host(), C - A @ B.T)
 
 

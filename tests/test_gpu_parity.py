@@ -60,8 +60,12 @@ def test_golden(name):
     pred = interp.predict(xs, x, alpha)
     assert pred.shape == (len(xs),)
     assert relmax(pred, g['predict_mean']) < mean_tol(cond)
-    # the reference's own compressed vector through our predict: isolates the fused K* contraction
-    assert relmax(interp.predict(xs, x, g['alpha']), g['predict_mean']) < 1e-12
+    # the reference's own compressed vector through our predict: isolates the fused K* contraction.  Only the
+    # summation order differs, so the bound is the dot product's own: eps * sum_j |K*_ij alpha_j| (which is
+    # 1e5 x the result for the ill-conditioned C1 fixture), not a condition-number bound
+    Ks_ref = g['Ks'] if 'Ks' in g else oracle.x2cov_chunked(oracle_terms(g, 'kernel'), xs, x)
+    dot_bound = 8 * EPS * np.max(np.abs(Ks_ref) @ np.abs(g['alpha'])) / np.max(np.abs(g['predict_mean']))
+    assert relmax(interp.predict(xs, x, g['alpha']), g['predict_mean']) < dot_bound + 1e-14
 
     mean, cov = interp.condition(xs, x, f)
     assert mean.shape == (len(xs),) and cov.shape == (len(xs), len(xs))
