@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py - condition+predict throughput of the GP hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+    build K(x,x; kernel+nugget) lower tiles -> blocked Cholesky (nb=512) -> alpha = K^-1 f (potrs)
+    -> posterior mean at M queries (fused K* alpha) -> posterior variance at M queries (V = L^-1 K*^T, col norms)
+i.e. Interpolator.condition_diag() without the host<->device copies (the PCIe-inclusive rate is in DESIGN.md).
+
+Workload at N=1 (config.workload): BASELINE.json configs[2] = C3, N=32768 D=3 jittered grid, SE + WhiteNoise
+nugget, nb=512, M=4096 queries - the configuration north_star quotes its target on ("the Cholesky trailing
+update at N=32768 on 1 MI355X").  `--workload c2` runs configs[1] (N=8192).
+
+value = algorithmic fp64 flops per step / wall time (TFLOP/s), flops = N^3/3 (potrf) + 2N^2 (potrs) + N^2 M
+(variance trsm) + 2MN (mean); kernel evaluations (exp) are NOT counted.  roofline = the dominant kernel, the
+trailing-update syrk: algorithmic flops sum_k n_k(n_k+1) nb over its launches / HIP-event time of those
+launches, recorded inside the timed region on the stream the kernel runs on; peak = 78.6 TFLOP/s (MI355X
+fp64 matrix, spec).  cpu_baseline = the numpy oracle (a port of the reference's algorithm) on a bounded
+sample of the same recipe, host cores of this box.
+
+N>1: one process per GPU (torch.distributed.run).  Round 1 runs independent replicas of the workload on
+every rank (scaling "weak", no data-path collective); the 2-D block-cyclic Cholesky over RCCL is the next
+row (DESIGN.md section f).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X fp64 matrix peak (spec)
+NB = 512
+
+WORKLOADS = {
+    # name: (grid, D, M, seed)  - SURVEY.md section 8d recipes
+    'c2': ((32, 16, 16), 3, 4096, 2),
+    'c3': ((32, 32, 32), 3, 4096, 3),
+}
+
+
+def make_inputs(n_side, m, seed):
+    """jittered grid in [0,1]^3, f = sin/cos product, SE sigma=1, ell_d = 2*spacing_d, white sigma_n = 1e-2"""
+    rng = np.random.default_rng(seed)
+    axes = [(np.arange(s) + 0.5) / s for s in n_side]
+    x = np.transpose([a.ravel() for a in np.meshgrid(*axes, indexing='ij')])
+    x = x + rng.uniform(-0.1, 0.1, x.shape) / np.array(n_side)
+    f = np.sin(3 * x[:, 0]) * np.cos(2 * x[:, 1]) + 0.5 * np.sin(4 * x[:, 2])
+    xs = rng.random((m, len(n_side)))
+    ell = tuple(2.0 / np.array(n_side, dtype=float))
+    return x, f, xs, ell
+
+
+def step_flops(n, m):
+    return n**3 / 3.0 + 2.0 * n * n + float(n) * n * m + 2.0 * m * n
+
+
+def trailing_flops(n, nb=NB):
+    """algorithmic lower-syrk flops of the trailing updates: sum_k n_k (n_k + 1) nb, n_k = N - k nb"""
+    pn = (n + 127) // 128 * 128
+    return float(sum((pn - k * nb) * (pn - k * nb + 1) * nb for k in range(1, (pn + nb - 1) // nb)))
+
+
+class GpuStep(object):
+    """device-resident inputs + one hot-path pass through the C-ABI"""
+
+    def __init__(self, x, f, xs, ell):
+        import ctypes
+        import mgpi_amd as mgpi
+        from mgpi_amd import _lib
+        self.ct, self.lib_mod = ctypes, _lib
+        self.ctx = mgpi.default_context()
+        self.lib = self.ctx.lib
+        self.n, self.m = len(x), len(xs)
+        k = mgpi.SquaredExponentialKernel(1.0, *ell)
+        nug = mgpi.WhiteNoiseKernel(1e-2)
+        self.kdesc = _lib.make_terms(k.terms())
+        self.sdesc = _lib.make_terms(k.terms() + nug.terms())
+        DM = _lib.DeviceMatrix
+        self.X = DM.from_host(self.ctx, x)
+        self.XS = DM.from_host(self.ctx, xs)
+        self.F = DM.from_host(self.ctx, f)
+        self.L = DM(self.ctx, self.n, self.n, wide=True)
+        self.alpha = DM(self.ctx, self.n, 1)
+        self.mean = DM(self.ctx, self.m, 1)
+        self.var = DM(self.ctx, self.m, 1)
+        self.ctx.sync()
+
+    def run(self):
+        c, h, lib = self.lib_mod.check, self.ctx.handle, self.lib
+        c(lib.mgpi_cov_matrix_dev(h, self.X.handle, None, self.sdesc[0], self.sdesc[1], 1, self.L.handle))
+        c(lib.mgpi_potrf_dev(h, self.L.handle, None))
+        c(lib.mgpi_mat_copy(h, self.F.handle, self.alpha.handle))
+        c(lib.mgpi_potrs_dev(h, self.L.handle, self.alpha.handle))
+        c(lib.mgpi_predict_mean_dev(h, self.XS.handle, self.X.handle, self.kdesc[0], self.kdesc[1],
+                                    self.alpha.handle, self.mean.handle))
+        c(lib.mgpi_predict_var_dev(h, self.XS.handle, self.X.handle, self.kdesc[0], self.kdesc[1], self.L.handle, 0,
+                                   self.var.handle))
+
+
+def cpu_baseline(seed=7):
+    """numpy oracle ("port" of the reference algorithm: pair materialisation + LU inverse) on a bounded sample:
+    the same recipe at N=4096 (16x16x16 grid), M=512, one condition() = mean + full covariance"""
+    from oracle import mgpi_oracle as oracle
+    n_side, m = (16, 16, 16), 512
+    x, f, xs, ell = make_inputs(n_side, m, seed)
+    kernel, nugget = [oracle.term_se(1.0, *ell)], [oracle.term_white(1e-2)]
+    t0 = time.perf_counter()
+    oracle.condition(kernel, nugget, xs, x, f)
+    dt = time.perf_counter() - t0
+    n = len(x)
+    return {'value': step_flops(n, m) / dt / 1e12, 'unit': 'TFLOP/s', 'cores': os.cpu_count(), 'kind': 'port',
+            'sample': 'oracle.condition (numpy pair materialisation + LU inverse) at N=%d D=3 M=%d, same recipe; '
+                      '%.1f s wall, algorithmic flops counted as for the GPU step' % (n, m, dt),
+            'seconds': dt}
+
+
+def load_traffic(workload):
+    """HBM bytes per trailing-update launch from the committed rocprofv3 --pmc summary (profiles/), or None"""
+    path = os.path.join(ROOT, 'profiles', 'traffic.json')
+    try:
+        with open(path) as fh:
+            return json.load(fh).get(workload, {}).get('bytes_per_launch')
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    os.environ.setdefault('MGPI_DEVICE', str(local_rank))
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+
+    n_side, d, m, seed = WORKLOADS[args.workload]
+    x, f, xs, ell = make_inputs(n_side, m, seed + 100 * rank)
+    n = len(x)
+    step = GpuStep(x, f, xs, ell)
+    ctx = step.ctx
+
+    def fence():
+        ctx.sync()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step.run()
+    ctx.set_profile(True)           # HIP-event pairs around the trailing-update launches; no host sync
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.run()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    syrk_ms, syrk_launches = ctx.get_profile(0)
+    panel_ms, _ = ctx.get_profile(1)
+    potrf_ms, _ = ctx.get_profile(2)
+    ctx.set_profile(False)
+
+    if rank == 0:
+        flops = step_flops(n, m) * world
+        value = flops * args.steps / elapsed / 1e12
+        tflops_syrk = trailing_flops(n) * args.steps / (syrk_ms * 1e-3) / 1e12
+        out = {
+            'metric': 'condition+predict achieved fp64 TFLOP/s (wall-clock in ms_per_step) at N training points',
+            'value': value, 'unit': 'TFLOP/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': '%s: N=%d D=%d jittered grid, SquaredExponential + WhiteNoise nugget, blocked '
+                                   'Cholesky nb=%d, M=%d queries (mean+variance); per GPU%s'
+                                   % (args.workload.upper(), n, d, NB, m, '' if world == 1 else ', independent replicas'),
+                       'N': n, 'D': d, 'M': m, 'nb': NB, 'parallelism': 'replicas%d' % world},
+            'roofline': {'bound': 'mfma', 'achieved': tflops_syrk, 'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': tflops_syrk / PEAK_FP64_MFMA_TFLOPS, 'traffic': load_traffic(args.workload),
+                         'kernel': 'gemm_f64_kernel<128,128,NT,lower> (Cholesky trailing update, syrk)',
+                         'launches': int(syrk_launches), 'avg_launch_ms': syrk_ms / max(1, syrk_launches),
+                         'algorithmic_flops_per_step': trailing_flops(n)},
+            'stages_ms_per_step': {'potrf': potrf_ms / args.steps, 'potrf_trailing_update': syrk_ms / args.steps,
+                                   'potrf_panels': panel_ms / args.steps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

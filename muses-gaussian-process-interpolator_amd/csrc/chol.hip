@@ -19,44 +19,65 @@
 // rows under the exact-equality white noise, where the reference's inv raises LinAlgError - fail here too
 // instead of returning garbage.
 #define MGPI_PIVOT_TOL 2.2e-14   /* 100 eps */
-__global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int64_t lda, int64_t pivot_base,
-                                                    const double* __restrict__ diag0, int* __restrict__ info) {
-    __shared__ double L[IB][IB + 1];
-    __shared__ int bad;
-    const int tid = threadIdx.x;
-    if (tid == 0) bad = 0;
-    for (int idx = tid; idx < IB * IB; idx += 256) {
-        const int i = idx >> 6, j = idx & 63;
-        L[i][j] = (j <= i) ? A[i * lda + j] : 0.0;
-    }
+
+// broadcast lane `l` (compile-time constant after unrolling) of a double to the whole wave: two v_readlane_b32
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// One wave; lane i owns row i of the block in 64 registers (every register index below is a compile-time
+// constant after unrolling, so nothing goes to scratch).  Column k: every lane drops its entry of column k into
+// LDS, reads the pivot back as a broadcast, forms 1/sqrt(pivot), and applies the rank-1 update
+// a_i[j] -= (a_i[k] / pivot) * a_j[k] with the column read back as 16-byte broadcasts.  One LDS round trip per
+// column is the whole synchronisation (a single wave executes its LDS operations in order).
+__global__ __launch_bounds__(64) void potf2_kernel(double* __restrict__ A, int64_t lda, int64_t pivot_base,
+                                                   const double* __restrict__ diag0, int* __restrict__ info) {
+    __shared__ double T[IB][IB + 1];
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < IB; ++r) T[r][lane] = A[r * lda + lane];   // 64 independent loads in flight
+    const double dg = MGPI_PIVOT_TOL * fabs(diag0[lane]);
     __syncthreads();
-    for (int kk = 0; kk < IB; ++kk) {
-        const double d = L[kk][kk];
-        const bool ok = d > MGPI_PIVOT_TOL * fabs(diag0[kk]);   // false for NaN too
-        if (!ok) {
-            if (tid == 0 && bad == 0) bad = kk + 1;
-        }
-        const double s = ok ? sqrt(d) : 1.0;
-        __syncthreads();
-        // scale column kk
-        if (tid < IB) {
-            if (tid == kk) L[kk][kk] = s;
-            else if (tid > kk) L[tid][kk] = L[tid][kk] / s;
-        }
-        __syncthreads();
-        // rank-1 update of the trailing lower triangle: (i, j), kk < j <= i
-        const int rem = IB - 1 - kk;
-        for (int idx = tid; idx < rem * rem; idx += 256) {
-            const int i = kk + 1 + idx / rem, j = kk + 1 + idx % rem;
-            if (j <= i) L[i][j] -= L[i][kk] * L[j][kk];
-        }
-        __syncthreads();
+    double a[IB];
+#pragma unroll
+    for (int j = 0; j < IB; ++j) a[j] = (j <= lane) ? T[lane][j] : 0.0;
+    int bad = 0;
+    __shared__ __attribute__((aligned(16))) double col[2][IB];
+    __shared__ double dtol[IB];
+    dtol[lane] = dg;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < IB; ++k) {
+        const double raw = a[k];
+        col[k & 1][lane] = raw;
+        __syncthreads();                                   // one wave: s_waitcnt + a trivial barrier
+        const double d = col[k & 1][k];
+        const bool ok = d > dtol[k];                       // false for NaN too
+        if (!ok && bad == 0) bad = k + 1;
+        // 1/sqrt(pivot): hardware estimate + two Newton steps (the pivot chain is the critical path of the
+        // whole factorisation; a correctly rounded sqrt + divide would triple its length)
+        const double dd = ok ? d : 1.0;
+        double y = __builtin_amdgcn_rsq(dd);
+        y = fma(y * 0.5, fma(-dd * y, y, 1.0), y);
+        y = fma(y * 0.5, fma(-dd * y, y, 1.0), y);
+        const double t = (lane > k) ? raw * (y * y) : 0.0; // a_i[k] / pivot
+        a[k] = (lane == k) ? dd * y : ((lane > k) ? raw * y : 0.0);
+        // pull the whole column into registers in one batch (one LDS latency), then the FMAs
+        double cj[IB];
+#pragma unroll
+        for (int j = k + 1; j < IB; ++j) cj[j] = col[k & 1][j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = k + 1; j < IB; ++j) a[j] = fma(-t, cj[j], a[j]);
     }
-    for (int idx = tid; idx < IB * IB; idx += 256) {
-        const int i = idx >> 6, j = idx & 63;
-        A[i * lda + j] = L[i][j];
-    }
-    if (tid == 0 && bad != 0) {
+#pragma unroll
+    for (int j = 0; j < IB; ++j) T[lane][j] = (j <= lane) ? a[j] : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < IB; ++r) A[r * lda + lane] = T[r][lane];
+    if (lane == 0 && bad != 0) {
         const int cand = (int)(pivot_base + bad);
         int old = atomicCAS(info, 0, cand);
         while (old != 0 && old > cand) {
@@ -68,40 +89,88 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int6
 }
 
 int mgpi_launch_potf2(mgpi_ctx* ctx, double* A, int64_t lda, int64_t pivot_base, const double* diag0) {
-    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, pivot_base, diag0, ctx->d_info);
+    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(64), 0, ctx->stream, A, lda, pivot_base, diag0, ctx->d_info);
     MGPI_HIP_TRY(hipGetLastError());
     return 0;
 }
 
-// ---- panel trsm: X L_jj^T = A for a block of rows, 64 columns ---------------------------------------
-// one workgroup = 64 threads = 64 rows; the row lives in registers, L_jj in LDS (broadcast reads).
-// x_k = (a_k - sum_{m<k} x_m L[k][m]) / L[k][k]
-__global__ __launch_bounds__(64) void trsm_rows_kernel(const double* __restrict__ Ljj, int64_t ldl,
-                                                       double* __restrict__ A, int64_t lda) {
-    __shared__ double L[IB][IB];          // L[k][m]: row k read as a broadcast
-    __shared__ double T[IB][IB + 1];      // staging tile for coalesced HBM access
-    const int lane = threadIdx.x;
-    double* blk = A + (int64_t)blockIdx.x * IB * lda;
-    for (int r = 0; r < IB; ++r) {
-        L[r][lane] = Ljj[r * ldl + lane];
-        T[r][lane] = blk[r * lda + lane];
-    }
-    __syncthreads();
-    double x[IB];
-#pragma unroll
-    for (int k = 0; k < IB; ++k) x[k] = T[lane][k];
+// ---- 64-wide triangular block solves ---------------------------------------------------------------------
+// Both use the right-looking (column-sweep) form: once x_k is final, every later unknown subtracts its
+// coefficient times x_k.  The 63-k updates of a step are independent FMAs (no dependent chain), the
+// coefficients are LDS broadcasts read two at a time, and the division is a multiply by a reciprocal computed
+// once per block (LAPACK's dtrsm does the same).  The unknowns of one row/column live in 64 registers.
+
+// The coefficients of a step are pulled from LDS in batches of up to 32 (16 ds_read_b128 issued back to back,
+// one exposed LDS latency per batch): left to itself hipcc issued one ds_read + s_waitcnt per FMA and exposed
+// the LDS latency 2000 times.  The diagonal slot C[k][k] holds the reciprocal 1/c_kk.
+
+// forward sweep: solves sum_{m<=k} c[k][m] x_m = b_k.  Ct[k][m] (m > k) = coefficient of x_k in equation m.
+__device__ __forceinline__ void sweep_fwd(double (&x)[IB], const double (*Ct)[IB]) {
 #pragma unroll
     for (int k = 0; k < IB; ++k) {
-        double s = x[k];
 #pragma unroll
-        for (int m = 0; m < k; ++m) s -= x[m] * L[k][m];
-        x[k] = s / L[k][k];
+        for (int h = 0; h < 2; ++h) {
+            const int lo = (h == 0) ? (k & ~1) : 32, hi = (h == 0) ? 32 : IB;
+            if (k < hi && lo < hi) {
+                double c[32];
+#pragma unroll
+                for (int m = lo; m < hi; ++m) c[m - lo] = Ct[k][m];
+                __builtin_amdgcn_sched_barrier(0);
+                if (k >= lo && k < hi) x[k] *= c[k - lo];
+#pragma unroll
+                for (int m = (k + 1 > lo ? k + 1 : lo); m < hi; ++m) x[m] = fma(-c[m - lo], x[k], x[m]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+// backward sweep: solves sum_{m>=k} c[m][k] x_m = b_k.  Cr[k][m] (m < k) = coefficient of x_k in equation m.
+__device__ __forceinline__ void sweep_bwd(double (&x)[IB], const double (*Cr)[IB]) {
+#pragma unroll
+    for (int k = IB - 1; k >= 0; --k) {
+#pragma unroll
+        for (int h = 1; h >= 0; --h) {
+            const int lo = (h == 0) ? 0 : 32;
+            const int end = (k + 2) & ~1;                                  // one past the diagonal, rounded to a 16-byte pair
+            const int hi0 = (h == 0) ? (end < 32 ? end : 32) : end;
+            if (k >= lo && lo < hi0) {
+                double c[32];
+#pragma unroll
+                for (int m = lo; m < hi0; ++m) c[m - lo] = Cr[k][m];
+                __builtin_amdgcn_sched_barrier(0);
+                if (k >= lo && k < hi0) x[k] *= c[k - lo];
+#pragma unroll
+                for (int m = lo; m < (k < hi0 ? k : hi0); ++m) x[m] = fma(-c[m - lo], x[k], x[m]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+// panel trsm: X L_jj^T = A for 64-row blocks, 64 columns.  One workgroup = one wave = 64 rows; thread = row.
+// x_k = (a_k - sum_{m<k} x_m L[k][m]) / L[k][k]: a forward sweep with Ct[k][m] = L[m][k], i.e. L transposed.
+// Each thread streams its own row (512 contiguous bytes) straight from HBM/L2: no staging tile, 33 KB of LDS.
+__global__ __launch_bounds__(64) void trsm_rows_kernel(const double* __restrict__ Ljj, int64_t ldl,
+                                                       double* __restrict__ A, int64_t lda) {
+    __shared__ __attribute__((aligned(16))) double Lt[IB][IB];
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < IB; ++r) {   // Lt[k][m] = L[m][k]; 64 loads in flight; reciprocal on the diagonal
+        const double v = Ljj[r * ldl + lane];
+        Lt[lane][r] = (r == lane) ? 1.0 / v : v;
+    }
+    double* row = A + ((int64_t)blockIdx.x * IB + lane) * lda;
+    double x[IB];
+#pragma unroll
+    for (int k = 0; k < IB; k += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(row + k);
+        x[k] = v.x;
+        x[k + 1] = v.y;
     }
     __syncthreads();
+    sweep_fwd(x, Lt);
 #pragma unroll
-    for (int k = 0; k < IB; ++k) T[lane][k] = x[k];
-    __syncthreads();
-    for (int r = 0; r < IB; ++r) blk[r * lda + lane] = T[r][lane];
+    for (int k = 0; k < IB; k += 2) *reinterpret_cast<double2*>(row + k) = make_double2(x[k], x[k + 1]);
 }
 
 int mgpi_launch_trsm_rows(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double* A, int64_t lda, int64_t rows) {
@@ -112,45 +181,39 @@ int mgpi_launch_trsm_rows(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double*
     return 0;
 }
 
-// ---- multi-rhs 64-row block solve:  B <- L_jj^-1 B  (TRANS = false)  or  L_jj^-T B  (TRANS = true) ----
-// B is (64 x n) row-major; one thread per column of B, L_jj in LDS (broadcast), coalesced across threads.
+// multi-rhs 64-row block solve:  B <- L_jj^-1 B  (TRANS = false)  or  L_jj^-T B  (TRANS = true).
+// B is (64 x n) row-major; one thread per column of B (coalesced across threads), L_jj in LDS.
+//   L x = b   : forward sweep,  Ct[k][m] = L[m][k]  (L transposed)
+//   L^T x = b : backward sweep, Cr[k][m] = L[k][m]  (L as stored)
 template <bool TRANS>
-__global__ __launch_bounds__(256) void trsm_cols_kernel(const double* __restrict__ Ljj, int64_t ldl,
-                                                        double* __restrict__ B, int64_t ldb, int64_t n) {
-    __shared__ double L[IB][IB];
-    for (int idx = threadIdx.x; idx < IB * IB; idx += 256) L[idx >> 6][idx & 63] = Ljj[(idx >> 6) * ldl + (idx & 63)];
-    __syncthreads();
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= n) return;
+__global__ __launch_bounds__(64) void trsm_cols_kernel(const double* __restrict__ Ljj, int64_t ldl,
+                                                       double* __restrict__ B, int64_t ldb) {
+    __shared__ __attribute__((aligned(16))) double Ls[IB][IB];
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < IB; ++r) {
+        double v = Ljj[r * ldl + lane];   // L[r][lane]; reciprocal on the diagonal
+        if (r == lane) v = 1.0 / v;
+        if (TRANS) Ls[r][lane] = v;
+        else Ls[lane][r] = v;
+    }
+    double* col = B + (int64_t)blockIdx.x * 64 + lane;   // n is a multiple of 64 (tile-padded B)
     double x[IB];
 #pragma unroll
-    for (int k = 0; k < IB; ++k) x[k] = B[k * ldb + c];
-    if (!TRANS) {
+    for (int k = 0; k < IB; ++k) x[k] = col[k * ldb];
+    __syncthreads();
+    if (TRANS) sweep_bwd(x, Ls);
+    else sweep_fwd(x, Ls);
 #pragma unroll
-        for (int k = 0; k < IB; ++k) {
-            double s = x[k];
-#pragma unroll
-            for (int m = 0; m < k; ++m) s -= L[k][m] * x[m];
-            x[k] = s / L[k][k];
-        }
-    } else {
-#pragma unroll
-        for (int k = IB - 1; k >= 0; --k) {
-            double s = x[k];
-#pragma unroll
-            for (int m = k + 1; m < IB; ++m) s -= L[m][k] * x[m];
-            x[k] = s / L[k][k];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < IB; ++k) B[k * ldb + c] = x[k];
+    for (int k = 0; k < IB; ++k) col[k * ldb] = x[k];
 }
 
 int mgpi_launch_trsm_cols(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double* B, int64_t ldb, int64_t n, int trans) {
     if (n == 0) return 0;
-    dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    if (trans) hipLaunchKernelGGL(trsm_cols_kernel<true>, grid, block, 0, ctx->stream, Ljj, ldl, B, ldb, n);
-    else hipLaunchKernelGGL(trsm_cols_kernel<false>, grid, block, 0, ctx->stream, Ljj, ldl, B, ldb, n);
+    MGPI_REQUIRE(n % 64 == 0, "trsm_cols: n=%lld is not a multiple of 64", (long long)n);
+    dim3 grid((unsigned)(n / 64)), block(64);
+    if (trans) hipLaunchKernelGGL(trsm_cols_kernel<true>, grid, block, 0, ctx->stream, Ljj, ldl, B, ldb);
+    else hipLaunchKernelGGL(trsm_cols_kernel<false>, grid, block, 0, ctx->stream, Ljj, ldl, B, ldb);
     MGPI_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -213,17 +276,12 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
     hipLaunchKernelGGL(save_diag_kernel, dim3((unsigned)((pn + 255) / 256)), dim3(256), 0, ctx->stream, A, lda, pn,
                        ctx->d_diag);
     MGPI_HIP_TRY(hipGetLastError());
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (ctx->profile) {
-        MGPI_HIP_TRY(hipEventCreate(&t0));
-        MGPI_HIP_TRY(hipEventCreate(&t1));
-        MGPI_HIP_TRY(hipEventRecord(t0, ctx->stream));
-    }
+    mgpi_prof_begin(ctx, 2);
 
     for (int64_t r0 = 0; r0 < pn; r0 += nb) {
         const int64_t w = (pn - r0 < nb) ? (pn - r0) : nb;   // panel width
         // ---- panel: columns [r0, r0+w), rows [r0, pn); left-looking over 64-wide inner blocks
-        mgpi_prof_begin(ctx);
+        mgpi_prof_begin(ctx, 1);
         for (int64_t c0 = r0; c0 < r0 + w; c0 += IB) {
             const int64_t kk = c0 - r0;
             if (kk > 0) {
@@ -238,23 +296,14 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
         // ---- trailing update (lower tiles only): A22 -= P P^T, P = A[r0+w:pn, r0:r0+w]
         const int64_t t = pn - r0 - w;
         if (t > 0) {
-            mgpi_prof_begin(ctx);
+            mgpi_prof_begin(ctx, 0);
             const double* P = A + (r0 + w) * lda + r0;
             MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 1, t, t, w, P, lda, P, lda, A + (r0 + w) * lda + (r0 + w), lda));
             mgpi_prof_end(ctx, 0);
         }
     }
 
-    if (ctx->profile) {
-        MGPI_HIP_TRY(hipEventRecord(t1, ctx->stream));
-        MGPI_HIP_TRY(hipEventSynchronize(t1));
-        float f = 0.f;
-        MGPI_HIP_TRY(hipEventElapsedTime(&f, t0, t1));
-        ctx->prof[2].ms += f;
-        ctx->prof[2].launches += 1;
-        (void)hipEventDestroy(t0);
-        (void)hipEventDestroy(t1);
-    }
+    mgpi_prof_end(ctx, 2);
 
     hipLaunchKernelGGL(logdiag_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, n, ctx->d_scal);
     MGPI_HIP_TRY(hipGetLastError());
@@ -329,34 +378,43 @@ extern "C" int mgpi_trsm_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* B, int 
 
 // ---- single right-hand side: HBM-bound blocked trsv ------------------------------------------------------
 // forward, diagonal nb-block: y_b = L_bb^-1 f_b.  One workgroup; 64-wide sub-blocks; the solved part of y in LDS.
+// Per sub-block: (a) gemv with the already solved entries - lane = row, the 4 waves split the columns, each
+// lane streams its own row 16 bytes at a time (the 4 waves together consume whole 128-byte lines);
+// (b) 64-step substitution by wave 0 with the 64x64 diagonal tile in LDS and lane broadcasts by v_readlane.
 __global__ __launch_bounds__(256) void trsv_diag_fwd_kernel(const double* __restrict__ L, int64_t lda,
                                                             double* __restrict__ y, int w) {
     __shared__ double ys[4096];
     __shared__ double Ls[IB][IB + 1];
-    __shared__ double sums[IB];
+    __shared__ double part[4][IB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < w; i += 256) ys[i] = y[i];
     for (int c0 = 0; c0 < w; c0 += IB) {
-        // stage the 64x64 diagonal sub-block (coalesced)
-        for (int idx = tid; idx < IB * IB; idx += 256)
+#pragma unroll
+        for (int u = 0; u < IB * IB / 256; ++u) {   // 16 independent loads in flight
+            const int idx = tid + 256 * u;
             Ls[idx >> 6][idx & 63] = L[(int64_t)(c0 + (idx >> 6)) * lda + c0 + (idx & 63)];
-        __syncthreads();
-        // gemv part: sums[i] = sum_{m<c0} L[c0+i][m] y[m]; wave handles rows i = wave, wave+4, ..; lanes along m
-        for (int i = wave; i < IB; i += 4) {
-            const double* row = L + (int64_t)(c0 + i) * lda;
-            double s = 0.0;
-            for (int m = lane; m < c0; m += 64) s += row[m] * ys[m];
-            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-            if (lane == 0) sums[i] = s;
         }
         __syncthreads();
+        const double* row = L + (int64_t)(c0 + lane) * lda;
+        double s = 0.0;
+        for (int m0 = 2 * wave; m0 < c0; m0 += 64) {   // c0 is a multiple of 64: exactly 8 loads per trip, all in flight
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double2*>(row + m0 + 8 * u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u].x * ys[m0 + 8 * u] + v[u].y * ys[m0 + 8 * u + 1];
+        }
+        part[wave][lane] = s;
+        __syncthreads();
         if (wave == 0) {
-            double b = ys[c0 + lane] - sums[lane];
-            // 64x64 substitution, column sweep: after y_k is known every later row subtracts L[i][k] y_k
+            double b = ys[c0 + lane] - (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+            const double rd = 1.0 / Ls[lane][lane];
+            // rolled loop: k lives in an SGPR and indexes v_readlane directly, so the 64-step chain is
+            // ~5 dependent VALU ops per step with no LDS round trip
+#pragma unroll 4
             for (int k = 0; k < IB; ++k) {
-                const double yk = __shfl(b, k, 64) / Ls[k][k];
-                if (lane == k) b = yk;
-                else if (lane > k) b -= Ls[lane][k] * yk;
+                const double yk = readlane_f64(b, k) * readlane_f64(rd, k);
+                b = (lane == k) ? yk : ((lane > k) ? fma(-Ls[lane][k], yk, b) : b);
             }
             ys[c0 + lane] = b;
         }
@@ -374,20 +432,30 @@ __global__ __launch_bounds__(256) void trsv_diag_bwd_kernel(const double* __rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < w; i += 256) ys[i] = y[i];
     for (int c0 = w - IB; c0 >= 0; c0 -= IB) {
-        for (int idx = tid; idx < IB * IB; idx += 256)
+#pragma unroll
+        for (int u = 0; u < IB * IB / 256; ++u) {   // 16 independent loads in flight
+            const int idx = tid + 256 * u;
             Ls[idx >> 6][idx & 63] = L[(int64_t)(c0 + (idx >> 6)) * lda + c0 + (idx & 63)];
+        }
         __syncthreads();
         // x_j (j = c0+lane) needs sum_{i >= c0+64} L[i][j] x_i : column access, coalesced across lanes
         double s = 0.0;
-        for (int i = c0 + IB + wave; i < w; i += 4) s += L[(int64_t)i * lda + c0 + lane] * ys[i];
+        for (int i0 = c0 + IB + wave; i0 < w; i0 += 64) {   // (w - c0 - 64) is a multiple of 64: 16 loads per trip
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = L[(int64_t)(i0 + 4 * u) * lda + c0 + lane];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u] * ys[i0 + 4 * u];
+        }
         part[wave][lane] = s;
         __syncthreads();
         if (wave == 0) {
             double b = ys[c0 + lane] - (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+            const double rd = 1.0 / Ls[lane][lane];
+#pragma unroll 4
             for (int k = IB - 1; k >= 0; --k) {
-                const double xk = __shfl(b, k, 64) / Ls[k][k];
-                if (lane == k) b = xk;
-                else if (lane < k) b -= Ls[k][lane] * xk;
+                const double xk = readlane_f64(b, k) * readlane_f64(rd, k);
+                b = (lane == k) ? xk : ((lane < k) ? fma(-Ls[k][lane], xk, b) : b);
             }
             ys[c0 + lane] = b;
         }
@@ -428,7 +496,13 @@ __global__ __launch_bounds__(256) void trsv_update_bwd_kernel(const double* __re
     const int64_t j = (int64_t)blockIdx.x * IB + lane;
     double s = 0.0;
     if (j < cols)
-        for (int i = wave; i < w; i += 4) s += Lb[(int64_t)i * lda + j] * xs[i];
+        for (int i0 = wave; i0 < w; i0 += 64) {   // w is a multiple of 64: 16 independent loads per trip
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = Lb[(int64_t)(i0 + 4 * u) * lda + j];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u] * xs[i0 + 4 * u];
+        }
     part[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && j < cols) y[j] -= part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];

@@ -45,14 +45,13 @@ extern "C" int mgpi_ctx_create(int device_id, int nb, mgpi_ctx** out) {
     MGPI_HIP_TRY(hipSetDevice(device_id));
     mgpi_ctx* c = new (std::nothrow) mgpi_ctx();
     if (!c) { mgpi_set_error("mgpi_ctx_create: out of host memory"); return MGPI_ERR_ALLOC; }
-    memset(c, 0, sizeof(*c));
+    memset((void*)c, 0, sizeof(*c));
+    c->prof = new mgpi_prof_slot[3]();
     c->device = device_id;
     c->nb = nb;
     MGPI_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     MGPI_HIP_TRY(hipEventCreate(&c->ev0));
     MGPI_HIP_TRY(hipEventCreate(&c->ev1));
-    MGPI_HIP_TRY(hipEventCreate(&c->pev0));
-    MGPI_HIP_TRY(hipEventCreate(&c->pev1));
     MGPI_HIP_TRY(hipMalloc((void**)&c->d_info, 64));
     MGPI_HIP_TRY(hipMalloc((void**)&c->d_scal, 4096 * sizeof(double)));
     MGPI_HIP_TRY(hipMemset(c->d_info, 0, 64));
@@ -70,8 +69,11 @@ extern "C" int mgpi_ctx_destroy(mgpi_ctx* ctx) {
     (void)hipFree(ctx->d_scal);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
-    (void)hipEventDestroy(ctx->pev0);
-    (void)hipEventDestroy(ctx->pev1);
+    for (int s = 0; s < 3; ++s) {
+        for (hipEvent_t e : ctx->prof[s].begin) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ctx->prof[s].end) (void)hipEventDestroy(e);
+    }
+    delete[] ctx->prof;
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -103,30 +105,52 @@ extern "C" int mgpi_ctx_toc(mgpi_ctx* ctx, double* ms) {
 
 extern "C" int mgpi_ctx_set_profile(mgpi_ctx* ctx, int on) {
     MGPI_REQUIRE(ctx != nullptr, "mgpi_ctx_set_profile: null ctx");
+    MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->profile = on;
-    memset(ctx->prof, 0, sizeof(ctx->prof));
+    for (int s = 0; s < 3; ++s) {
+        ctx->prof[s].used = 0;
+        ctx->prof[s].ms = 0.0;
+        ctx->prof[s].launches = 0;
+    }
     return 0;
 }
 
+// sums the recorded event pairs (after draining the stream)
 extern "C" int mgpi_ctx_get_profile(mgpi_ctx* ctx, int which, double* ms, int64_t* launches) {
     MGPI_REQUIRE(ctx != nullptr && which >= 0 && which < 3, "mgpi_ctx_get_profile: bad argument");
-    if (ms) *ms = ctx->prof[which].ms;
-    if (launches) *launches = ctx->prof[which].launches;
+    MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    mgpi_prof_slot& p = ctx->prof[which];
+    double total = 0.0;
+    for (size_t i = 0; i < p.used; ++i) {
+        float f = 0.f;
+        MGPI_HIP_TRY(hipEventElapsedTime(&f, p.begin[i], p.end[i]));
+        total += f;
+    }
+    p.ms = total;
+    p.launches = (int64_t)p.used;
+    if (ms) *ms = total;
+    if (launches) *launches = p.launches;
     return 0;
 }
 
-// per-launch HIP-event timing (synchronous; only when profiling is switched on)
-void mgpi_prof_begin(mgpi_ctx* ctx) {
-    if (ctx->profile) (void)hipEventRecord(ctx->pev0, ctx->stream);
+// HIP-event pair around a launch (or a group of launches) on the ctx stream; nothing waits on the host
+void mgpi_prof_begin(mgpi_ctx* ctx, int slot) {
+    if (!ctx->profile) return;
+    mgpi_prof_slot& p = ctx->prof[slot];
+    if (p.used == p.begin.size()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        p.begin.push_back(a);
+        p.end.push_back(b);
+    }
+    (void)hipEventRecord(p.begin[p.used], ctx->stream);
 }
 void mgpi_prof_end(mgpi_ctx* ctx, int slot) {
     if (!ctx->profile) return;
-    (void)hipEventRecord(ctx->pev1, ctx->stream);
-    (void)hipEventSynchronize(ctx->pev1);
-    float f = 0.f;
-    (void)hipEventElapsedTime(&f, ctx->pev0, ctx->pev1);
-    ctx->prof[slot].ms += f;
-    ctx->prof[slot].launches += 1;
+    mgpi_prof_slot& p = ctx->prof[slot];
+    if (p.used >= p.end.size()) return;
+    (void)hipEventRecord(p.end[p.used], ctx->stream);
+    p.used += 1;
 }
 
 int mgpi_ensure_work(mgpi_ctx* ctx, size_t bytes) {

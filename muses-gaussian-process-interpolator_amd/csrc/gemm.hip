@@ -9,15 +9,21 @@
 // MFMA f64 16x16x4 operand map (cdna_hip_programming.md section 3): lane l supplies A[l&15][l>>4] and
 // B[l>>4][l&15]; it receives D[(l>>4) + 4r][l&15], r = 0..3.
 //
-// LDS images (doubles; strides chosen so each 32-lane half of a ds_read_b64 touches 32 distinct 8-byte banks):
-//   row-major operand  ([row][k], k contiguous in HBM):  stride 18 : row*18 mod 32 is a permutation of the evens
-//   k-major operand    ([k][col], col contiguous in HBM): stride BN+16: consecutive k rows land 32 banks apart
+// LDS images (conflict-free by construction; SQ_LDS_BANK_CONFLICT measured 0 on the syrk kernel):
+//   row-major operand ([row][k], k contiguous in HBM): 16 doubles = 128 B per row, no padding, the eight 16-byte
+//     chunks of a row XOR-swizzled by (row>>1)&7.  A lane fetches TWO consecutive k of its row with one
+//     ds_read_b128 (chunk 4h+g of lane group g = lane>>4) and feeds them to two successive MFMAs, so MFMA s of a
+//     pair contracts over k = 8h + 2g + s.  Within each 16-lane group of a ds_read_b128 the 16 chunk addresses
+//     fall on 16 distinct 4-bank slots (rows r, r^1 differ in bank half, the XOR separates the row pairs).
+//   k-major operand ([k][col], col contiguous in HBM): stride BT+16 doubles; a lane reads single doubles at
+//     k = 8h + 2g + s, 16 consecutive columns per lane group.
 #include "mgpi_internal.h"
+#include <stdlib.h>
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 #define GEMM_BK 16
-#define GEMM_SR 18            // LDS row stride of a row-major operand tile
+#define GEMM_SR 16            // LDS row stride of a row-major operand tile (swizzled, unpadded)
 
 template <int BT, bool KMAJOR>
 struct TileGeom {
@@ -54,15 +60,23 @@ __device__ __forceinline__ void tile_store(double* __restrict__ lds, int tid,
             *reinterpret_cast<double2*>(lds + kr * (BT + 16) + 2 * c2) = r[s];
         } else {
             const int row = idx >> 3, k2 = idx & 7;
-            *reinterpret_cast<double2*>(lds + row * GEMM_SR + 2 * k2) = r[s];
+            *reinterpret_cast<double2*>(lds + row * GEMM_SR + 2 * (k2 ^ ((row >> 1) & 7))) = r[s];
         }
     }
 }
 
-// fragment element (t = index along the tile edge, k = contraction index) of an LDS operand image
+// fragments of one half stage (h = 0, 1 -> k in [8h, 8h+8)) for the tile row/column t: f[0] feeds the first MFMA
+// of the pair (k = 8h + 2g), f[1] the second (k = 8h + 2g + 1); g = lane >> 4
 template <int BT, bool KMAJOR>
-__device__ __forceinline__ double frag(const double* __restrict__ lds, int t, int k) {
-    return KMAJOR ? lds[k * (BT + 16) + t] : lds[t * GEMM_SR + k];
+__device__ __forceinline__ void frag_pair(const double* __restrict__ lds, int t, int h, int g, double (&f)[2]) {
+    if (KMAJOR) {
+        f[0] = lds[(8 * h + 2 * g) * (BT + 16) + t];
+        f[1] = lds[(8 * h + 2 * g + 1) * (BT + 16) + t];
+    } else {
+        const double2 v = *reinterpret_cast<const double2*>(lds + t * GEMM_SR + 2 * ((4 * h + g) ^ ((t >> 1) & 7)));
+        f[0] = v.x;
+        f[1] = v.y;
+    }
 }
 
 // linear lower-triangle tile index -> (i, j), j <= i
@@ -74,11 +88,54 @@ __device__ __forceinline__ void tri_decode(int64_t idx, int& ti, int& tj) {
     tj = (int)(idx - (int64_t)i * (i + 1) / 2);
 }
 
+// Tile order for L2 reuse.  The tile list is cut into bands of GEMM_BAND tile rows; inside a band the order is
+// column-major, so 64 consecutive tiles (= what one XCD has in flight: 32 CUs x 2 workgroups) form an 8 x 8 block
+// that shares 8 A slabs and 8 B slabs through that XCD's 4 MiB L2.  With plain row-major order every tile
+// pulled its own B slab from beyond L2 (measured: 54 % L2 hit rate, 2.5x the algorithmic HBM bytes).
+#define GEMM_BAND 8
+template <bool LOWER>
+__device__ __forceinline__ void tile_decode(int64_t idx, int tm, int tn, int& ti, int& tj) {
+    constexpr int S = GEMM_BAND;
+    if (!LOWER) {
+        const int64_t per_band = (int64_t)S * tn;
+        const int band = (int)(idx / per_band);
+        const int within = (int)(idx - band * per_band);
+        const int rows = (tm - band * S < S) ? (tm - band * S) : S;
+        tj = within / rows;
+        ti = band * S + within - tj * rows;
+        return;
+    }
+    // lower triangle: band b holds rows [bS, bS + rows): rows * bS tiles left of the diagonal block (column-major)
+    // plus the rows x rows lower triangle on the diagonal
+    const int64_t full = (int64_t)(tm / S);                       // number of complete bands
+    auto cum = [](int64_t b) { return (int64_t)S * S * b * (b - 1) / 2 + (int64_t)S * (S + 1) / 2 * b; };
+    int64_t band;
+    if (idx >= cum(full)) {
+        band = full;
+    } else {
+        band = (int64_t)((-0.5 * S + sqrt(0.25 * S * S + 2.0 * S * S * (double)idx)) / (double)(S * S));
+        while (band + 1 <= full && cum(band + 1) <= idx) ++band;
+        while (cum(band) > idx) --band;
+    }
+    const int rows = (tm - (int)band * S < S) ? (tm - (int)band * S) : S;
+    const int64_t within = idx - cum(band);
+    const int64_t left = (int64_t)rows * band * S;
+    if (within < left) {
+        tj = (int)(within / rows);
+        ti = (int)(band * S + within - (int64_t)tj * rows);
+    } else {
+        int ii, jj;
+        tri_decode(within - left, ii, jj);
+        ti = (int)(band * S) + ii;
+        tj = (int)(band * S) + jj;
+    }
+}
+
 template <int BM, int BN, bool AK, bool BKM, bool LOWER>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(int64_t k, const double* __restrict__ A, int64_t lda,
                                                           const double* __restrict__ B, int64_t ldb,
-                                                          double* __restrict__ C, int64_t ldc, int tiles_n,
-                                                          int64_t ntiles) {
+                                                          double* __restrict__ C, int64_t ldc, int tiles_m,
+                                                          int tiles_n, int64_t ntiles) {
     constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
     constexpr int FM = WM / 16, FN = WN / 16;   // MFMA tiles per wave
     using GA = TileGeom<BM, AK>;
@@ -94,45 +151,52 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(int64_t k, const doubl
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
     int ti, tj;
-    if (LOWER) {
-        tri_decode(bid, ti, tj);
-    } else {
-        ti = (int)(bid / tiles_n);
-        tj = (int)(bid % tiles_n);
-    }
+    tile_decode<LOWER>(bid, tiles_m, tiles_n, ti, tj);
     const int64_t m0 = (int64_t)ti * BM, n0 = (int64_t)tj * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int fr = lane & 15, fq = lane >> 4;
 
+    double2 ra[GA::vecs], rb[GB::vecs];
+    tile_load<BM, AK>(A, lda, m0, 0, tid, ra);
+    tile_load<BN, BKM>(B, ldb, n0, 0, tid, rb);
+
+    // The accumulators start from the C tile and the MFMAs add (-A) B: the result C - A B is then stored straight
+    // from the accumulators.  (An epilogue that re-read C cost one exposed HBM round trip per tile.)
+    // D[(lane>>4) + 4r][lane&15]
     double4_t acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
-    double2 ra[GA::vecs], rb[GB::vecs];
-    tile_load<BM, AK>(A, lda, m0, 0, tid, ra);
-    tile_load<BN, BKM>(B, ldb, n0, 0, tid, rb);
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[i][j][r] = C[(m0 + wr * WM + i * 16 + fq + 4 * r) * ldc + n0 + wc * WN + j * 16 + fr];
     tile_store<BM, AK>(lds, tid, ra);
     tile_store<BN, BKM>(lds + GA::doubles, tid, rb);
     __syncthreads();
 
-    // one LDS stage = 4 MFMA k-steps on the wave's FM x FN accumulator tiles
+    // one LDS stage = 2 half stages x 2 MFMA k-steps on the wave's FM x FN accumulator tiles
     auto compute_stage = [&](const double* __restrict__ la, const double* __restrict__ lb) {
 #pragma unroll
-        for (int ks = 0; ks < GEMM_BK / 4; ++ks) {
-            double af[FM], bf[FN];
+        for (int h = 0; h < 2; ++h) {
+            double af[FM][2], bf[FN][2];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) af[i] = frag<BM, AK>(la, wr * WM + i * 16 + fr, ks * 4 + fq);
+            for (int i = 0; i < FM; ++i) {
+                frag_pair<BM, AK>(la, wr * WM + i * 16 + fr, h, fq, af[i]);
+                af[i][0] = -af[i][0];
+                af[i][1] = -af[i][1];
+            }
 #pragma unroll
-            for (int j = 0; j < FN; ++j) bf[j] = frag<BN, BKM>(lb, wc * WN + j * 16 + fr, ks * 4 + fq);
+            for (int j = 0; j < FN; ++j) frag_pair<BN, BKM>(lb, wc * WN + j * 16 + fr, h, fq, bf[j]);
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][s2], bf[j][s2], acc[i][j], 0, 0, 0);
         }
     };
 
@@ -143,6 +207,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(int64_t k, const doubl
         tile_load<BM, AK>(A, lda, m0, (kt + 1) * GEMM_BK, tid, ra);
         tile_load<BN, BKM>(B, ldb, n0, (kt + 1) * GEMM_BK, tid, rb);
         compute_stage(lds + cur * STAGE, lds + cur * STAGE + GA::doubles);
+        // keep the staging writes (and the vmcnt waits in front of them) behind the stage's MFMAs: the loads then
+        // have the whole stage (64 MFMAs = 4096 cycles) to land
+        __builtin_amdgcn_sched_barrier(0);
         tile_store<BM, AK>(lds + (cur ^ 1) * STAGE, tid, ra);
         tile_store<BN, BKM>(lds + (cur ^ 1) * STAGE + GA::doubles, tid, rb);
         __syncthreads();
@@ -152,18 +219,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(int64_t k, const doubl
         compute_stage(lds + cur * STAGE, lds + cur * STAGE + GA::doubles);
     }
 
-    // epilogue: C -= acc.  D[(lane>>4) + 4r][lane&15]
+    // epilogue: the accumulators hold C - A B
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t row = m0 + wr * WM + i * 16 + fq + 4 * r;
-                const int64_t col = n0 + wc * WN + j * 16 + fr;
-                double* p = C + row * ldc + col;
-                *p = *p - acc[i][j][r];
-            }
+            for (int r = 0; r < 4; ++r)
+                C[(m0 + wr * WM + i * 16 + fq + 4 * r) * ldc + n0 + wc * WN + j * 16 + fr] = acc[i][j][r];
 }
 
 template <int BM, int BN, bool AK, bool BKM, bool LOWER>
@@ -173,7 +236,7 @@ static int launch_one(mgpi_ctx* ctx, int64_t m, int64_t n, int64_t k, const doub
     const int64_t ntiles = LOWER ? tm * (tm + 1) / 2 : tm * tn;
     MGPI_REQUIRE(ntiles > 0 && ntiles < (int64_t)2147483647, "gemm: tile count %lld out of range", (long long)ntiles);
     hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, AK, BKM, LOWER>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, k,
-                       A, lda, B, ldb, C, ldc, (int)tn, ntiles);
+                       A, lda, B, ldb, C, ldc, (int)tm, (int)tn, ntiles);
     MGPI_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -217,7 +280,7 @@ extern "C" int mgpi_gemm_nt_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat
     const int64_t m = C->prows, n = mgpi_roundup(C->cols, 64) <= C->pcols ? (C->pcols) : C->pcols;
     const int64_t k = A->pcols < B->pcols ? A->pcols : B->pcols;
     MGPI_REQUIRE(A->prows >= m && B->prows >= n, "mgpi_gemm_nt_dev: operand padding smaller than the result's");
-    mgpi_prof_begin(ctx);
+    mgpi_prof_begin(ctx, 0);
     int st = mgpi_launch_gemm(ctx, 0, 0, lower_only, m, n, k, A->d, A->ld, B->d, B->ld, C->d, C->ld);
     mgpi_prof_end(ctx, 0);
     return st;

@@ -9,16 +9,22 @@
 #define MGPI_TILE   128      // padding granule of matrix dims and the gemm macro-tile
 #define MGPI_IB      64      // inner (panel) block of the two-level Cholesky / trsm
 
-struct mgpi_prof_slot { double ms; int64_t launches; };
+#include <vector>
+// per-slot HIP-event pairs recorded around launches (no host sync while recording); read by get_profile
+struct mgpi_prof_slot {
+    std::vector<hipEvent_t> begin, end;
+    size_t used;
+    double ms;          // filled by mgpi_prof_collect
+    int64_t launches;
+};
 
 struct mgpi_ctx {
     int device;
     int nb;                       // outer Cholesky block
     hipStream_t stream;
     hipEvent_t ev0, ev1;          // tic/toc
-    hipEvent_t pev0, pev1;        // per-kernel profiling
     int profile;
-    mgpi_prof_slot prof[3];
+    mgpi_prof_slot* prof;         // [3]: 0 trailing update, 1 panel, 2 whole potrf
     int* d_info;                  // device: first failing pivot (0 = none)
     double* d_scal;               // device scratch scalars (logdet partials etc.), 4096 doubles
     double* d_diag;               // diag(K) before factoring (pivot threshold), grown on demand
@@ -97,5 +103,5 @@ int mgpi_launch_trsm_rows(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double*
 // multi-rhs 64-row block solves on B (64 x n): trans=0: L_jj^-1 B, trans=1: L_jj^-T B
 int mgpi_launch_trsm_cols(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double* B, int64_t ldb, int64_t n, int trans);
 
-void mgpi_prof_begin(mgpi_ctx* ctx);
+void mgpi_prof_begin(mgpi_ctx* ctx, int slot);
 void mgpi_prof_end(mgpi_ctx* ctx, int slot);

@@ -6,7 +6,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mgpi_amd as mgpi
 from mgpi_amd import _lib
 
