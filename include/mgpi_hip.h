@@ -89,6 +89,13 @@ int  mgpi_mat_copy(mgpi_ctx* ctx, const mgpi_mat* src, mgpi_mat* dst);
 /* fill the strict upper triangle from the lower one (square), for downloads of a lower-only build */
 int  mgpi_mat_symmetrize(mgpi_ctx* ctx, mgpi_mat* m);
 
+/* zero the strict upper triangle (square): turns an in-place Cholesky result into a clean lower factor */
+int  mgpi_mat_tril(mgpi_ctx* ctx, mgpi_mat* m);
+/* diag (n x 1 vector) <- diagonal of the square matrix m */
+int  mgpi_mat_diag(mgpi_ctx* ctx, const mgpi_mat* m, mgpi_mat* diag);
+/* m[i][j] <- m[i][j] / (s[i] * s[j]), s an (n x 1) vector: covariance -> correlation (interpolators.py:321) */
+int  mgpi_mat_unscale(mgpi_ctx* ctx, mgpi_mat* m, const mgpi_mat* s);
+
 /* ---- (i) kernel operators ---------------------------------------------------------- */
 /* Kernel.cov: row-paired, x1 and x2 both (p, d) row-major host arrays -> out (p,) host */
 int  mgpi_cov_paired(mgpi_ctx* ctx, const double* x1, const double* x2, int64_t p, int d,

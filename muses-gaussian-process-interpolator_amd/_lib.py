@@ -63,6 +63,9 @@ _SIGNATURES = {
     'mgpi_mat_devptr': (_vp, [_vp]),
     'mgpi_mat_copy': (ctypes.c_int, [_vp, _vp, _vp]),
     'mgpi_mat_symmetrize': (ctypes.c_int, [_vp, _vp]),
+    'mgpi_mat_tril': (ctypes.c_int, [_vp, _vp]),
+    'mgpi_mat_diag': (ctypes.c_int, [_vp, _vp, _vp]),
+    'mgpi_mat_unscale': (ctypes.c_int, [_vp, _vp, _vp]),
     'mgpi_mat_view': (ctypes.c_int, [_vp, c_int64, c_int64, c_int64, c_int64, ctypes.POINTER(_vp)]),
     'mgpi_cov_paired': (ctypes.c_int, [_vp, _vp, _vp, c_int64, ctypes.c_int, ctypes.POINTER(KernelDesc), ctypes.c_int, _vp]),
     'mgpi_cov_matrix': (ctypes.c_int, [_vp, _vp, c_int64, _vp, c_int64, ctypes.c_int, ctypes.POINTER(KernelDesc), ctypes.c_int, _vp]),

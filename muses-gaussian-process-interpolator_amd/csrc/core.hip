@@ -310,6 +310,50 @@ extern "C" int mgpi_mat_symmetrize(mgpi_ctx* ctx, mgpi_mat* m) {
     return 0;
 }
 
+__global__ void tril_kernel(double* a, int64_t ld, int64_t n) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j < n && j > i) a[i * ld + j] = 0.0;
+}
+
+extern "C" int mgpi_mat_tril(mgpi_ctx* ctx, mgpi_mat* m) {
+    MGPI_REQUIRE(ctx && m, "mgpi_mat_tril: null pointer");
+    MGPI_REQUIRE(m->rows == m->cols, "mgpi_mat_tril: matrix is not square");
+    const int64_t n = m->prows < m->pcols ? m->prows : m->pcols;
+    MGPI_REQUIRE(n <= 65535 * 64, "mgpi_mat_tril: matrix too large");
+    hipLaunchKernelGGL(tril_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, ctx->stream, m->d, m->ld, n);
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+__global__ void diag_kernel(const double* a, int64_t ld, int64_t n, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i * ld + i];
+}
+
+extern "C" int mgpi_mat_diag(mgpi_ctx* ctx, const mgpi_mat* m, mgpi_mat* diag) {
+    MGPI_REQUIRE(ctx && m && diag, "mgpi_mat_diag: null pointer");
+    MGPI_REQUIRE(m->rows == m->cols && diag->rows == m->rows && diag->ld == 1, "mgpi_mat_diag: shapes do not conform");
+    hipLaunchKernelGGL(diag_kernel, dim3((unsigned)((m->rows + 255) / 256)), dim3(256), 0, ctx->stream, m->d, m->ld, m->rows, diag->d);
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+__global__ void unscale_kernel(double* a, int64_t ld, int64_t n, const double* __restrict__ s) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j < n) a[i * ld + j] = a[i * ld + j] / (s[i] * s[j]);
+}
+
+extern "C" int mgpi_mat_unscale(mgpi_ctx* ctx, mgpi_mat* m, const mgpi_mat* s) {
+    MGPI_REQUIRE(ctx && m && s, "mgpi_mat_unscale: null pointer");
+    MGPI_REQUIRE(m->rows == m->cols && s->rows == m->rows && s->ld == 1, "mgpi_mat_unscale: shapes do not conform");
+    MGPI_REQUIRE(m->rows <= 65535, "mgpi_mat_unscale: matrix too large");
+    hipLaunchKernelGGL(unscale_kernel, dim3((unsigned)((m->rows + 255) / 256), (unsigned)m->rows), dim3(256), 0, ctx->stream,
+                       m->d, m->ld, m->rows, s->d);
+    MGPI_HIP_TRY(hipGetLastError());
+    m->factored = 0;
+    return 0;
+}
+
 int mgpi_make_terms(const mgpi_kernel_desc* terms, int nterms, int d, mgpi_terms_dev* out) {
     MGPI_REQUIRE(terms != nullptr && out != nullptr, "kernel terms: null pointer");
     MGPI_REQUIRE(nterms >= 1 && nterms <= MGPI_MAX_TERMS, "kernel terms: nterms=%d outside [1,%d]", nterms, MGPI_MAX_TERMS);

@@ -262,6 +262,59 @@ class Interpolator(object):
             print('    time : %.6f sec' % (time.time() - t0))
         return out
 
+    #--- realisations of the conditioned process (interpolators.py:306-324)
+
+    def rvs(self, target_x, source_x, source_f, size=1, rng=None):
+        """draw `size` realisations of f(target_x) | source_f: mean + MVN(0, cov/outer(s,s)) * s with
+        s = sqrt(diag cov) - the rescaling the reference describes at interpolators.py:319-321.
+
+        The reference's own rvs raises TypeError (its helper lacks @staticmethod), so this
+        follows its documented intent.  The correlation matrix is factored on the GPU (Cholesky instead of
+        numpy's SVD sampler) and the standard normals come from numpy: `rng` may be a numpy Generator, by
+        default the global numpy state is used like np.random.multivariate_normal does."""
+        gp = self._fit_checked(source_x, source_f, False)
+        ctx = self.context
+        XS = gp._targets(target_x)
+        m = XS.rows
+        mean = gp.mean_dev(XS).to_host().reshape(-1)
+        cov = gp.cov_dev(XS)
+        svec = _lib.DeviceMatrix(ctx, m, 1)
+        _lib.check(ctx.lib.mgpi_mat_diag(ctx.handle, cov.handle, svec.handle))
+        var = svec.to_host().reshape(-1)
+        if not np.all(var > 0):
+            raise np.linalg.LinAlgError('conditioned covariance has a non-positive diagonal entry')
+        scales = np.sqrt(var)
+        svec.upload(scales)
+        _lib.check(ctx.lib.mgpi_mat_unscale(ctx.handle, cov.handle, svec.handle))       # correlation matrix
+        corr = _lib.DeviceMatrix(ctx, m, m, wide=True)
+        # a conditioned covariance is only positive SEMI-definite where targets sit on (nearly) noise-free
+        # sources; like a jittered Cholesky sampler, retry with a growing diagonal shift
+        jitter, last = 0.0, None
+        for attempt in range(6):
+            _lib.check(ctx.lib.mgpi_mat_copy(ctx.handle, cov.handle, corr.handle))
+            if jitter > 0.0:
+                host = corr.to_host()
+                host[np.diag_indices(m)] += jitter
+                corr.upload(host)
+            try:
+                _lib.check(ctx.lib.mgpi_potrf_dev(ctx.handle, corr.handle, None))
+                last = None
+                break
+            except _lib.NotPositiveDefinite as err:
+                last = err
+                jitter = 1e-12 if jitter == 0.0 else jitter * 100.0
+        if last is not None:
+            raise np.linalg.LinAlgError('conditioned covariance is not positive definite even with jitter %g' % jitter)
+        _lib.check(ctx.lib.mgpi_mat_tril(ctx.handle, corr.handle))
+        normal = rng.standard_normal if rng is not None else np.random.standard_normal
+        z = normal((int(size), m))
+        Z = _lib.DeviceMatrix.from_host(ctx, -z, wide=True)           # the gemm computes C -= A B^T
+        R = _lib.DeviceMatrix(ctx, int(size), m, wide=True)            # zero-initialised
+        _lib.check(ctx.lib.mgpi_gemm_nt_dev(ctx.handle, Z.handle, corr.handle, R.handle, 0))
+        return mean + R.to_host() * scales
+
+    sample = rvs
+
     #--- marginal likelihood (interpolators.py:331-343)
 
     def loglikelihood(self, source_x, source_f, verbose=False):

@@ -67,6 +67,19 @@ class Kernel(object):
                                            desc, count, out.ctypes.data))
         return out
 
+    def __call__(self, x1, x2=None):
+        """additive (BASELINE.json north_star asks for it; the reference has no __call__): the PAIRWISE matrix
+        K[i, j] = cov(x1[i], x2[j]), shape (n1, n2) - what Interpolator._x2cov builds; x2=None means x2 = x1"""
+        a = _lib.as_f64(x1, ndim=2)
+        b = a if x2 is None else _lib.as_f64(x2, ndim=2)
+        assert b.shape[1] == a.shape[1], 'conflicting number of dimensions for x1 and x2'
+        desc, count = _lib.make_terms(self.terms())
+        ctx = _lib.default_context()
+        out = np.empty((len(a), len(b)), dtype=np.float64)
+        _lib.check(ctx.lib.mgpi_cov_matrix(ctx.handle, a.ctypes.data, len(a), None if x2 is None else b.ctypes.data,
+                                           len(b), a.shape[1], desc, count, out.ctypes.data))
+        return out
+
     # -- parameter views -------------------------------------------------------------------------
 
     @property
