@@ -149,6 +149,22 @@ int  mgpi_gemm_nt_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* B, mgpi_
  * r0/c0/rows/cols must be multiples of 64 or reach the padded edge */
 int  mgpi_mat_view(const mgpi_mat* m, int64_t r0, int64_t c0, int64_t rows, int64_t cols, mgpi_mat** out);
 
+/* non-owning handle over external device memory (rows x cols doubles, row stride ld, 16-byte aligned), e.g. a
+ * communication buffer of the multi-GPU driver; factored != 0 marks it as holding a Cholesky factor */
+int  mgpi_mat_wrap(mgpi_ctx* ctx, void* devptr, int64_t rows, int64_t cols, int64_t ld, int factored, mgpi_mat** out);
+/* out (all padded entries) = k(X1[i], X2[j]) for i < n1_valid, j < n2_valid, zero elsewhere: a local block of the
+ * block-cyclic K; the driver sets the unit diagonal of padded global indices */
+int  mgpi_cov_block_dev(mgpi_ctx* ctx, const mgpi_mat* X1, int64_t n1_valid, const mgpi_mat* X2, int64_t n2_valid,
+                        const mgpi_kernel_desc* terms, int nterms, mgpi_mat* out);
+/* C (m x n) -= A (m x k) * B (k x n)   (row-major B: the update of the multi-rhs triangular solve) */
+int  mgpi_gemm_nn_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* B, mgpi_mat* C);
+/* A <- A L^-T : panel trsm with a factored diagonal block L (w x w) on a block of rows A (m x w) */
+int  mgpi_trsm_right_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* A);
+/* single-vector half-solve with a factored diagonal block (<= 4096 rows): L y = b (trans=0) / L^T x = b (trans=1) */
+int  mgpi_trsv_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* v, int trans);
+/* y -= A x (trans=0) or y -= A^T x (trans=1); x, y vectors (ld == 1) */
+int  mgpi_gemv_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* x, mgpi_mat* y, int trans);
+
 /* measured throughput probes used by bench.py's roofline leg (not part of the hot path) */
 int  mgpi_probe_mfma_f64(mgpi_ctx* ctx, int iters, double* tflops);
 int  mgpi_probe_hbm(mgpi_ctx* ctx, int64_t bytes, int iters, double* read_gbs, double* write_gbs);

@@ -78,6 +78,12 @@ _SIGNATURES = {
     'mgpi_predict_var_dev': (ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(KernelDesc), ctypes.c_int, _vp, c_int64, _vp]),
     'mgpi_condition_cov_dev': (ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(KernelDesc), ctypes.c_int, _vp, _vp]),
     'mgpi_gemm_nt_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int]),
+    'mgpi_mat_wrap': (ctypes.c_int, [_vp, _vp, c_int64, c_int64, c_int64, ctypes.c_int, ctypes.POINTER(_vp)]),
+    'mgpi_cov_block_dev': (ctypes.c_int, [_vp, _vp, c_int64, _vp, c_int64, ctypes.POINTER(KernelDesc), ctypes.c_int, _vp]),
+    'mgpi_gemm_nn_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    'mgpi_trsm_right_dev': (ctypes.c_int, [_vp, _vp, _vp]),
+    'mgpi_trsv_dev': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
+    'mgpi_gemv_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int]),
     'mgpi_probe_mfma_f64': (ctypes.c_int, [_vp, ctypes.c_int, c_double_p]),
     'mgpi_probe_hbm': (ctypes.c_int, [_vp, c_int64, ctypes.c_int, c_double_p, c_double_p]),
     'mgpi_ctx_set_profile': (ctypes.c_int, [_vp, ctypes.c_int]),

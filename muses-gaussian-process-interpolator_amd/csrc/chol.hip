@@ -564,3 +564,61 @@ extern "C" int mgpi_potrs(mgpi_ctx* ctx, const mgpi_mat* L, const double* b, int
     mgpi_mat_free(B);
     return st;
 }
+
+// ---- block-level entry points for the multi-GPU (2-D block-cyclic) driver ---------------------------------
+// A <- A L^-T for a factored diagonal block L (w x w) and a block of rows A (m x w): the panel trsm of the
+// right-looking factorisation, applied by the ranks that own the blocks below a remote diagonal block.
+extern "C" int mgpi_trsm_right_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* A) {
+    MGPI_REQUIRE(ctx && L && A, "mgpi_trsm_right_dev: null pointer");
+    MGPI_REQUIRE(L->rows == L->cols && A->cols == L->rows, "mgpi_trsm_right_dev: A has %lld columns, L is %lld x %lld",
+                 (long long)A->cols, (long long)L->rows, (long long)L->cols);
+    MGPI_REQUIRE(L->rows % IB == 0 && A->prows % IB == 0, "mgpi_trsm_right_dev: dimensions must be multiples of %d", IB);
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    const int64_t w = L->rows, m = A->prows;
+    for (int64_t c0 = 0; c0 < w; c0 += IB) {
+        if (c0 > 0)   // A[:, c0:c0+64] -= A[:, 0:c0] * L[c0:c0+64, 0:c0]^T
+            MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, m, IB, c0, A->d, A->ld, L->d + c0 * L->ld, L->ld, A->d + c0, A->ld));
+        MGPI_TRY(mgpi_launch_trsm_rows(ctx, L->d + c0 * L->ld + c0, L->ld, A->d + c0, A->ld, m));
+    }
+    return 0;
+}
+
+// one triangular half-solve with a factored diagonal block on an (n x 1) vector: L y = b (trans = 0), L^T x = b (1)
+extern "C" int mgpi_trsv_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* v, int trans) {
+    MGPI_REQUIRE(ctx && L && v, "mgpi_trsv_dev: null pointer");
+    MGPI_REQUIRE(L->rows == L->cols && v->ld == 1 && v->prows >= L->prows, "mgpi_trsv_dev: shapes do not conform");
+    MGPI_REQUIRE(L->prows % IB == 0 && L->prows <= 4096, "mgpi_trsv_dev: block of %lld rows (need a multiple of %d, <= 4096)",
+                 (long long)L->prows, IB);
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    if (trans) hipLaunchKernelGGL(trsv_diag_bwd_kernel, dim3(1), dim3(256), 0, ctx->stream, L->d, L->ld, v->d, (int)L->prows);
+    else hipLaunchKernelGGL(trsv_diag_fwd_kernel, dim3(1), dim3(256), 0, ctx->stream, L->d, L->ld, v->d, (int)L->prows);
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// y -= A x (trans = 0, A is m x k, x (k), y (m))   or   y -= A^T x (trans = 1, x (m), y (k)); vectors have ld == 1
+extern "C" int mgpi_gemv_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* x, mgpi_mat* y, int trans) {
+    MGPI_REQUIRE(ctx && A && x && y, "mgpi_gemv_dev: null pointer");
+    MGPI_REQUIRE(x->ld == 1 && y->ld == 1, "mgpi_gemv_dev: x and y must be vectors");
+    const int64_t m = A->prows, k = A->pcols;
+    MGPI_REQUIRE((trans ? x->prows >= m && y->prows >= k : x->prows >= k && y->prows >= m), "mgpi_gemv_dev: vector too short");
+    MGPI_REQUIRE(k % 128 == 0 && m % 64 == 0, "mgpi_gemv_dev: A must be tile padded");
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    if (!trans) {
+        for (int64_t c0 = 0; c0 < k; c0 += 4096) {   // x chunk lives in LDS
+            const int w = (int)((k - c0 < 4096) ? (k - c0) : 4096);
+            int64_t blocks = (m + 3) / 4;
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(trsv_update_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, A->d + c0, A->ld,
+                               x->d + c0, w, y->d, m);
+        }
+    } else {
+        for (int64_t r0 = 0; r0 < m; r0 += 4096) {
+            const int w = (int)((m - r0 < 4096) ? (m - r0) : 4096);
+            hipLaunchKernelGGL(trsv_update_bwd_kernel, dim3((unsigned)((k + IB - 1) / IB)), dim3(256), 0, ctx->stream,
+                               A->d + r0 * A->ld, A->ld, x->d + r0, w, y->d, k);
+        }
+    }
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
+}

@@ -239,6 +239,26 @@ extern "C" int mgpi_mat_view(const mgpi_mat* m, int64_t r0, int64_t c0, int64_t 
     return 0;
 }
 
+// non-owning handle over caller-provided device memory (e.g. a torch.distributed communication buffer): exactly
+// rows x cols, row stride ld; the caller guarantees the dimensions it later passes to tile kernels are padded
+extern "C" int mgpi_mat_wrap(mgpi_ctx* ctx, void* devptr, int64_t rows, int64_t cols, int64_t ld, int factored, mgpi_mat** out) {
+    MGPI_REQUIRE(ctx && devptr && out, "mgpi_mat_wrap: null pointer");
+    MGPI_REQUIRE(rows >= 1 && cols >= 1 && ld >= cols, "mgpi_mat_wrap: bad shape %lld x %lld (ld %lld)", (long long)rows,
+                 (long long)cols, (long long)ld);
+    MGPI_REQUIRE(((uintptr_t)devptr % 16) == 0, "mgpi_mat_wrap: pointer must be 16-byte aligned");
+    mgpi_mat* v = new (std::nothrow) mgpi_mat();
+    if (!v) { mgpi_set_error("mgpi_mat_wrap: out of host memory"); return MGPI_ERR_ALLOC; }
+    v->ctx = ctx;
+    v->rows = v->prows = rows;
+    v->cols = v->pcols = cols;
+    v->ld = ld;
+    v->d = (double*)devptr;
+    v->owns = 0;
+    v->factored = factored;
+    *out = v;
+    return 0;
+}
+
 extern "C" int mgpi_mat_shape(const mgpi_mat* m, int64_t* rows, int64_t* cols, int64_t* ld) {
     MGPI_REQUIRE(m != nullptr, "mgpi_mat_shape: null matrix");
     if (rows) *rows = m->rows;

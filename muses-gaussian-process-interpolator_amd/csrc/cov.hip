@@ -178,3 +178,22 @@ extern "C" int mgpi_cov_paired(mgpi_ctx* ctx, const double* x1, const double* x2
     MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
 }
+
+// block form for the multi-GPU driver: out (every padded entry) = k(X1[i], X2[j]) for i < n1_valid, j < n2_valid,
+// zero elsewhere (padded global indices get their unit diagonal from the driver, which knows the global layout)
+extern "C" int mgpi_cov_block_dev(mgpi_ctx* ctx, const mgpi_mat* X1, int64_t n1_valid, const mgpi_mat* X2, int64_t n2_valid,
+                                  const mgpi_kernel_desc* terms, int nterms, mgpi_mat* out) {
+    MGPI_REQUIRE(ctx && X1 && X2 && out, "mgpi_cov_block_dev: null pointer");
+    MGPI_REQUIRE(X1->cols == X2->cols, "conflicting number of dimensions for x1 and x2 (%lld vs %lld)", (long long)X1->cols,
+                 (long long)X2->cols);
+    MGPI_REQUIRE(n1_valid >= 0 && n2_valid >= 0 && n1_valid <= X1->prows && n2_valid <= X2->prows &&
+                     n1_valid <= out->prows && n2_valid <= out->pcols,
+                 "mgpi_cov_block_dev: valid extents %lld x %lld exceed the operands", (long long)n1_valid, (long long)n2_valid);
+    MGPI_REQUIRE(out->prows % COV_T == 0 && out->pcols % COV_T == 0, "mgpi_cov_block_dev: out must be tile padded");
+    mgpi_terms_dev t;
+    MGPI_TRY(mgpi_make_terms(terms, nterms, (int)X1->cols, &t));
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    out->factored = 0;
+    return mgpi_launch_cov(ctx, t, X1->d, X1->ld, n1_valid, out->prows, X2->d, X2->ld, n2_valid, out->pcols, 0, 0, 0,
+                           out->d, out->ld);
+}

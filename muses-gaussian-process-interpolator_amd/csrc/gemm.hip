@@ -285,3 +285,16 @@ extern "C" int mgpi_gemm_nt_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat
     mgpi_prof_end(ctx, 0);
     return st;
 }
+
+// C (m x n) -= A (m x k) * B (k x n), all row-major: the update form of the multi-rhs triangular solves
+extern "C" int mgpi_gemm_nn_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* B, mgpi_mat* C) {
+    MGPI_REQUIRE(ctx && A && B && C, "mgpi_gemm_nn_dev: null pointer");
+    MGPI_REQUIRE(A->cols == B->rows && C->rows == A->rows && C->cols == B->cols,
+                 "mgpi_gemm_nn_dev: shapes A %lldx%lld, B %lldx%lld, C %lldx%lld do not conform", (long long)A->rows,
+                 (long long)A->cols, (long long)B->rows, (long long)B->cols, (long long)C->rows, (long long)C->cols);
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    const int64_t m = C->prows, n = C->pcols;
+    const int64_t k = A->pcols < B->prows ? A->pcols : B->prows;
+    MGPI_REQUIRE(A->prows >= m && B->pcols >= n, "mgpi_gemm_nn_dev: operand padding smaller than the result's");
+    return mgpi_launch_gemm(ctx, 0, 1, 0, m, n, k, A->d, A->ld, B->d, B->ld, C->d, C->ld);
+}

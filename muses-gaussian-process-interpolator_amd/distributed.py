@@ -1,0 +1,500 @@
+"""Multi-GPU dense GP: 2-D block-cyclic right-looking Cholesky over one node.
+
+One process per GPU, launched by ``torch.distributed.run``; ``torch.distributed`` (backend ``nccl`` = RCCL over
+xGMI on the GPU box, ``gloo`` in the CPU tests) is the transport, torch tensors are the communication
+buffers, and every tile operation goes through a *tile backend*:
+
+  * ``HipTileBackend`` (this file): wraps the tensors' device memory with ``mgpi_mat_wrap`` and runs the same
+    HIP kernels as the single-GPU path (cov tile build, fp64-MFMA gemm, potf2/trsm panel, trsv pieces).
+  * the CPU tests inject a numpy backend built on the oracle (tests/dist_cpu_backend.py) so that the
+    schedule below - ownership, broadcast order, index bookkeeping - is exercised with gloo at world size
+    2 and 4 without a GPU.  The product never constructs that backend.
+
+Distribution: K is cut into nb x nb blocks (nb = the outer Cholesky block, 512); block (I, J) lives on grid
+position (I mod P, J mod Q) of a P x Q process grid (1x1, 1x2, 2x2, 2x4).  Only a broadcast pattern is needed
+(no all-reduce): per block step k
+  1. the owner factors the diagonal block and broadcasts it down its process column,
+  2. that column's ranks solve their panel blocks  A[I][k] <- A[I][k] L_kk^-T,
+  3. the panel is broadcast along process rows, then (transposed role) along process columns,
+  4. every rank updates its local trailing blocks  A[I][J] -= L[I][k] L[J][k]^T  (I >= J > k) on fp64 MFMA.
+The solves use a replicated right-hand side: per block step one small reduce inside a process row (forward)
+or column (backward) and one world broadcast of the nb solved entries.
+"""
+import ctypes
+import math
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ['ProcessGrid', 'HipTileBackend', 'DistributedGP', 'choose_grid']
+
+
+def choose_grid(world):
+    """P x Q with P <= Q, as square as possible: 1->1x1, 2->1x2, 4->2x2, 8->2x4"""
+    p = int(math.floor(math.sqrt(world)))
+    while world % p:
+        p -= 1
+    return p, world // p
+
+
+class ProcessGrid(object):
+    """rank <-> (p, q) on a P x Q grid (row-major), with one process group per grid row and per grid column"""
+
+    def __init__(self, dist, P=None, Q=None, always_communicate=False):
+        self.dist = dist
+        self.always = bool(always_communicate)   # tests: issue the collectives even inside size-1 groups
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        if P is None:
+            P, Q = choose_grid(self.world)
+        assert P * Q == self.world, 'grid %dx%d does not match world size %d' % (P, Q, self.world)
+        self.P, self.Q = P, Q
+        self.p, self.q = divmod(self.rank, Q)
+        # every rank must create every group, in the same order
+        self.row_groups = [dist.new_group([pp * Q + qq for qq in range(Q)]) for pp in range(P)]
+        self.col_groups = [dist.new_group([pp * Q + qq for pp in range(P)]) for qq in range(Q)]
+
+    def rank_of(self, p, q):
+        return p * self.Q + q
+
+    def bcast_row(self, tensor, p, src_q):
+        """broadcast inside grid row p from column src_q (only ranks of that row call this)"""
+        if self.Q > 1 or self.always:
+            self.dist.broadcast(tensor, src=self.rank_of(p, src_q), group=self.row_groups[p])
+
+    def bcast_col(self, tensor, q, src_p):
+        if self.P > 1 or self.always:
+            self.dist.broadcast(tensor, src=self.rank_of(src_p, q), group=self.col_groups[q])
+
+    def bcast_world(self, tensor, src):
+        if self.world > 1 or self.always:
+            self.dist.broadcast(tensor, src=src)
+
+    def reduce_row(self, tensor, p, dst_q):
+        if self.Q > 1 or self.always:
+            self.dist.reduce(tensor, dst=self.rank_of(p, dst_q), op=self.dist.ReduceOp.SUM, group=self.row_groups[p])
+
+    def reduce_col(self, tensor, q, dst_p):
+        if self.P > 1 or self.always:
+            self.dist.reduce(tensor, dst=self.rank_of(dst_p, q), op=self.dist.ReduceOp.SUM, group=self.col_groups[q])
+
+
+class HipTileBackend(object):
+    """tile operations on torch CUDA tensors through libmgpi_hip.so (the same kernels as the 1-GPU path)"""
+
+    def __init__(self, torch, ctx=None):
+        self.torch = torch
+        self.ctx = ctx if ctx is not None else _lib.default_context()
+        self.lib = self.ctx.lib
+        self.device = torch.device('cuda', self.ctx.device)
+        # make OUR stream torch's current stream: torch's own ops on the communication buffers (zeros, copy_,
+        # add_) are then enqueued in order with the tile kernels, and NCCL collectives order themselves against
+        # the current stream, so no host-side synchronisation is needed for correctness
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.ExternalStream(self.lib.mgpi_ctx_stream(self.ctx.handle), device=self.device)
+        torch.cuda.set_stream(self.stream)
+
+    # -- memory -------------------------------------------------------------------------------------------
+    def zeros(self, rows, cols=None):
+        shape = (rows,) if cols is None else (rows, cols)
+        return self.torch.zeros(shape, dtype=self.torch.float64, device=self.device)
+
+    def from_numpy(self, a):
+        return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+
+    def to_numpy(self, t):
+        self.fence()
+        return t.detach().cpu().numpy()
+
+    def fence(self):
+        """order our stream against torch's: all queued tile kernels and all torch/NCCL work are complete"""
+        self.ctx.sync()
+        self.torch.cuda.synchronize(self.device)
+
+    def _wrap(self, t, factored=0):
+        """mgpi_mat view of a 2-D tensor (or a vector): row stride from the tensor, no copy"""
+        if t.dim() == 1:
+            rows, cols, ld = t.shape[0], 1, 1
+            assert t.stride(0) == 1
+        else:
+            rows, cols = t.shape
+            ld = t.stride(0)
+            assert t.stride(1) == 1, 'tile views must be row-major'
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.mgpi_mat_wrap(self.ctx.handle, ctypes.c_void_p(t.data_ptr()), rows, cols, ld, factored,
+                                          ctypes.byref(h)))
+        return h
+
+    def _free(self, *handles):
+        for h in handles:
+            self.lib.mgpi_mat_free(h)
+
+    # -- tile kernels -------------------------------------------------------------------------------------
+    def cov(self, x_rows, x_cols, terms, out, n_rows_valid, n_cols_valid):
+        """out[i][j] = k(x_rows[i], x_cols[j]) for i < n_rows_valid, j < n_cols_valid, zero elsewhere"""
+        desc, count = _lib.make_terms(terms)
+        XR = _lib.DeviceMatrix.from_host(self.ctx, x_rows)
+        XC = _lib.DeviceMatrix.from_host(self.ctx, x_cols)
+        h = self._wrap(out)
+        try:
+            _lib.check(self.lib.mgpi_cov_block_dev(self.ctx.handle, XR.handle, n_rows_valid, XC.handle, n_cols_valid,
+                                                   desc, count, h))
+        finally:
+            self._free(h)
+        self.ctx.sync()
+
+    def potrf(self, block):
+        """in-place Cholesky of a diagonal block; returns (info, sum log diag)"""
+        h = self._wrap(block)
+        logdet = ctypes.c_double(0.0)
+        try:
+            st = self.lib.mgpi_potrf_dev(self.ctx.handle, h, ctypes.byref(logdet))
+        finally:
+            self._free(h)
+        if st < 0:
+            _lib.check(st)
+        return st, 0.5 * logdet.value
+
+    def trsm_right(self, lkk, rows):
+        a, b = self._wrap(lkk, 1), self._wrap(rows)
+        try:
+            _lib.check(self.lib.mgpi_trsm_right_dev(self.ctx.handle, a, b))
+        finally:
+            self._free(a, b)
+
+    def gemm_nt(self, c, a, b):
+        hc, ha, hb = self._wrap(c), self._wrap(a), self._wrap(b)
+        try:
+            _lib.check(self.lib.mgpi_gemm_nt_dev(self.ctx.handle, ha, hb, hc, 0))
+        finally:
+            self._free(hc, ha, hb)
+
+    def gemm_nn(self, c, a, b):
+        hc, ha, hb = self._wrap(c), self._wrap(a), self._wrap(b)
+        try:
+            _lib.check(self.lib.mgpi_gemm_nn_dev(self.ctx.handle, ha, hb, hc))
+        finally:
+            self._free(hc, ha, hb)
+
+    def trsm_left(self, lkk, rhs):
+        a, b = self._wrap(lkk, 1), self._wrap(rhs)
+        try:
+            _lib.check(self.lib.mgpi_trsm_dev(self.ctx.handle, a, b, 0))
+        finally:
+            self._free(a, b)
+
+    def trsv(self, lkk, vec, trans):
+        a, b = self._wrap(lkk, 1), self._wrap(vec)
+        try:
+            _lib.check(self.lib.mgpi_trsv_dev(self.ctx.handle, a, b, int(trans)))
+        finally:
+            self._free(a, b)
+
+    def gemv(self, a, x, y, trans):
+        ha, hx, hy = self._wrap(a), self._wrap(x), self._wrap(y)
+        try:
+            _lib.check(self.lib.mgpi_gemv_dev(self.ctx.handle, ha, hx, hy, int(trans)))
+        finally:
+            self._free(ha, hx, hy)
+
+    def predict_mean(self, xs, x, terms, alpha):
+        desc, count = _lib.make_terms(terms)
+        XS = _lib.DeviceMatrix.from_host(self.ctx, xs)
+        X = _lib.DeviceMatrix.from_host(self.ctx, x)
+        A = _lib.DeviceMatrix.from_host(self.ctx, alpha)
+        out = _lib.DeviceMatrix(self.ctx, len(xs), 1)
+        _lib.check(self.lib.mgpi_predict_mean_dev(self.ctx.handle, XS.handle, X.handle, desc, count, A.handle, out.handle))
+        return out.to_host().reshape(-1)
+
+    def colsq(self, v):
+        """column sums of squares of a local slab, as a numpy vector"""
+        self.fence()
+        return (v * v).sum(dim=0).cpu().numpy()
+
+    def prior_diag(self, xs, terms):
+        desc, count = _lib.make_terms(terms)
+        xs = _lib.as_f64(xs, ndim=2)
+        out = np.empty(len(xs))
+        _lib.check(self.lib.mgpi_cov_paired(self.ctx.handle, xs.ctypes.data, xs.ctypes.data, len(xs), xs.shape[1], desc, count,
+                                            out.ctypes.data))
+        return out
+
+
+class DistributedGP(object):
+    """K(x,x; kernel+nugget) built, factored and solved on a P x Q grid of GPUs"""
+
+    def __init__(self, grid, backend, source_x, kernel_terms, solve_terms, nb=512):
+        self.g = grid
+        self.be = backend
+        self.nb = int(nb)
+        self.x = _lib.as_f64(source_x, ndim=2)
+        self.n, self.d = self.x.shape
+        self.kernel_terms = list(kernel_terms)
+        self.solve_terms = list(solve_terms)
+        g = grid
+        lcm = g.P * g.Q // math.gcd(g.P, g.Q)
+        self.nblk = int(math.ceil(self.n / float(self.nb)))
+        self.nblk = (self.nblk + lcm - 1) // lcm * lcm            # every rank owns the same number of blocks
+        self.np_ = self.nblk * self.nb
+        self.row_blocks = list(range(g.p, self.nblk, g.P))          # global block rows owned, ascending
+        self.col_blocks = list(range(g.q, self.nblk, g.Q))
+        self.mloc = len(self.row_blocks) * self.nb
+        self.nloc = len(self.col_blocks) * self.nb
+        self.A = None
+        self.logdet = None
+        self.alpha = None
+
+    # -- index helpers ------------------------------------------------------------------------------------
+    def _global_index(self, blocks):
+        return (np.asarray(blocks)[:, None] * self.nb + np.arange(self.nb)[None, :]).reshape(-1)
+
+    def _first_local(self, blocks, bound):
+        """number of local blocks with global index <= bound"""
+        return int(np.searchsorted(np.asarray(blocks), bound, side='right'))
+
+    # -- communication (fenced on both sides: tile kernels run on our stream, collectives on torch's) ---------
+    def _bcast_row(self, t, p, src_q):
+        self.be.fence()
+        self.g.bcast_row(t, p, src_q)
+        self.be.fence()
+
+    def _bcast_col(self, t, q, src_p):
+        self.be.fence()
+        self.g.bcast_col(t, q, src_p)
+        self.be.fence()
+
+    def _bcast_world(self, t, src):
+        self.be.fence()
+        self.g.bcast_world(t, src)
+        self.be.fence()
+
+    def _reduce_row(self, t, p, dst_q):
+        self.be.fence()
+        self.g.reduce_row(t, p, dst_q)
+        self.be.fence()
+
+    def _reduce_col(self, t, q, dst_p):
+        self.be.fence()
+        self.g.reduce_col(t, q, dst_p)
+        self.be.fence()
+
+    # -- build --------------------------------------------------------------------------------------------
+    def build(self):
+        be, nb = self.be, self.nb
+        gi = self._global_index(self.row_blocks)
+        gj = self._global_index(self.col_blocks)
+        nvr = int(np.sum(gi < self.n))
+        nvc = int(np.sum(gj < self.n))
+        xr = np.zeros((self.mloc, self.d))
+        xc = np.zeros((self.nloc, self.d))
+        xr[:nvr] = self.x[gi[:nvr]]
+        xc[:nvc] = self.x[gj[:nvc]]
+        self.A = be.zeros(self.mloc, self.nloc)
+        be.cov(xr, xc, self.solve_terms, self.A, nvr, nvc)
+        # padded global indices (>= n) get a unit diagonal so the padded matrix stays positive definite
+        for li, I in enumerate(self.row_blocks):
+            if (I + 1) * nb > self.n and I % self.g.Q == self.g.q:
+                lj = self.col_blocks.index(I)
+                t0 = max(0, self.n - I * nb)
+                self.A[li * nb + t0:(li + 1) * nb, lj * nb + t0:(lj + 1) * nb].diagonal().fill_(1.0)
+        be.fence()
+
+    # -- factor -------------------------------------------------------------------------------------------
+    def factor(self):
+        g, be, nb = self.g, self.be, self.nb
+        A = self.A
+        info_first = 0
+        logdiag = 0.0
+        for k in range(self.nblk):
+            pk, qk = k % g.P, k % g.Q
+            kr, kc = k // g.P, k // g.Q                      # local block indices on the owners
+            i0 = self._first_local(self.row_blocks, k)       # local row blocks [i0:) have I > k
+            j0 = self._first_local(self.col_blocks, k)
+            mt = self.mloc - i0 * nb                         # local trailing rows
+            nt = self.nloc - j0 * nb
+            # 1. diagonal block
+            lkk = be.zeros(nb, nb)
+            if g.q == qk:
+                if g.p == pk:
+                    blk = A[kr * nb:(kr + 1) * nb, kc * nb:(kc + 1) * nb]
+                    info, ld = be.potrf(blk)
+                    if info > 0 and info_first == 0:
+                        info_first = k * nb + info
+                    logdiag += ld
+                    lkk.copy_(blk)
+                self._bcast_col(lkk, qk, pk)
+                # 2. panel trsm on this process column
+                if mt > 0:
+                    be.trsm_right(lkk, A[i0 * nb:, kc * nb:(kc + 1) * nb])
+            # 3. panel along process rows
+            wrow = be.zeros(max(mt, 1), nb)
+            if mt > 0:
+                if g.q == qk:
+                    wrow.copy_(A[i0 * nb:, kc * nb:(kc + 1) * nb])
+                self._bcast_row(wrow, g.p, qk)
+            # 4. transposed role along process columns: rank (pr, q) holds L[J][k] for J = q mod Q, J = pr mod P
+            wcol = be.zeros(max(nt, 1), nb)
+            if nt > 0:
+                for pr in range(g.P):
+                    mine = [(jl, J) for jl, J in enumerate(self.col_blocks) if J > k and J % g.P == pr]
+                    if not mine:
+                        continue
+                    buf = be.zeros(len(mine) * nb, nb)
+                    if g.p == pr:
+                        for s, (jl, J) in enumerate(mine):
+                            il = self.row_blocks.index(J)
+                            buf[s * nb:(s + 1) * nb].copy_(wrow[(il - i0) * nb:(il - i0 + 1) * nb])
+                    self._bcast_col(buf, g.q, pr)
+                    for s, (jl, J) in enumerate(mine):
+                        wcol[(jl - j0) * nb:(jl - j0 + 1) * nb].copy_(buf[s * nb:(s + 1) * nb])
+            # 5. local trailing update, one block column at a time: rows I >= J
+            if mt > 0 and nt > 0:
+                for jl in range(j0, len(self.col_blocks)):
+                    J = self.col_blocks[jl]
+                    il = self._first_local(self.row_blocks, J - 1)          # first local row block with I >= J
+                    if il >= len(self.row_blocks):
+                        continue
+                    be.gemm_nt(A[il * nb:, jl * nb:(jl + 1) * nb], wrow[(il - i0) * nb:], wcol[(jl - j0) * nb:(jl - j0 + 1) * nb])
+            be.fence()
+        # logdet and the first failing pivot, agreed by everyone
+        if g.world > 1:
+            s = self.be.from_numpy(np.array([logdiag]))
+            g.dist.all_reduce(s, op=g.dist.ReduceOp.SUM)
+            logdiag = float(self.be.to_numpy(s)[0])
+            m = self.be.from_numpy(np.array([float(-info_first) if info_first else -1e300]))
+            g.dist.all_reduce(m, op=g.dist.ReduceOp.MAX)      # max of (-info) = smallest failing pivot
+            worst = float(self.be.to_numpy(m)[0])
+            info_first = int(-worst) if worst > -1e299 else 0
+        if info_first:
+            raise _lib.NotPositiveDefinite(info_first, 'covariance is not positive definite! (pivot %d)' % info_first)
+        self.logdet = 2.0 * logdiag
+        return self.logdet
+
+    # -- solve (replicated right-hand side) -----------------------------------------------------------------
+    def solve(self, source_f):
+        g, be, nb = self.g, self.be, self.nb
+        A = self.A
+        f = np.zeros(self.np_)
+        f[:self.n] = _lib.as_f64(source_f).reshape(-1)
+        y = be.from_numpy(f)                                   # replicated, global order
+        ycol = be.zeros(self.nloc)                              # solved entries in local COLUMN order
+        # forward: L y = f
+        for k in range(self.nblk):
+            pk, qk = k % g.P, k % g.Q
+            kr, kc = k // g.P, k // g.Q
+            if g.p == pk:
+                s = be.zeros(nb)
+                jc = self._first_local(self.col_blocks, k - 1)  # local col blocks [0:jc) have J < k
+                if jc > 0:
+                    be.gemv(A[kr * nb:(kr + 1) * nb, :jc * nb], ycol[:jc * nb], s, 0)     # s = -sum_J L[k][J] y_J
+                self._reduce_row(s, pk, qk)
+                if g.q == qk:
+                    yk = y[k * nb:(k + 1) * nb]
+                    yk.add_(s)
+                    be.fence()
+                    be.trsv(A[kr * nb:(kr + 1) * nb, kc * nb:(kc + 1) * nb], yk, 0)
+                    be.fence()
+            yk = y[k * nb:(k + 1) * nb]
+            self._bcast_world(yk, g.rank_of(pk, qk))
+            if g.q == qk:
+                ycol[kc * nb:(kc + 1) * nb].copy_(yk)
+        # backward: L^T x = y
+        xrow = be.zeros(self.mloc)                              # solved entries in local ROW order
+        for k in range(self.nblk - 1, -1, -1):
+            pk, qk = k % g.P, k % g.Q
+            kr, kc = k // g.P, k // g.Q
+            if g.q == qk:
+                s = be.zeros(nb)
+                i0 = self._first_local(self.row_blocks, k)      # local row blocks [i0:) have I > k
+                if i0 < len(self.row_blocks):
+                    be.gemv(A[i0 * nb:, kc * nb:(kc + 1) * nb], xrow[i0 * nb:], s, 1)     # s = -sum_I L[I][k]^T x_I
+                self._reduce_col(s, qk, pk)
+                if g.p == pk:
+                    xk = y[k * nb:(k + 1) * nb]
+                    xk.add_(s)
+                    be.fence()
+                    be.trsv(A[kr * nb:(kr + 1) * nb, kc * nb:(kc + 1) * nb], xk, 1)
+                    be.fence()
+            xk = y[k * nb:(k + 1) * nb]
+            self._bcast_world(xk, g.rank_of(pk, qk))
+            if g.p == pk:
+                xrow[kr * nb:(kr + 1) * nb].copy_(xk)
+        self.alpha = be.to_numpy(y)[:self.n].copy()
+        return self.alpha
+
+    # -- predict ------------------------------------------------------------------------------------------
+    def mean(self, target_x):
+        """posterior mean, queries sharded over all ranks (x and alpha are replicated), result replicated"""
+        g, be = self.g, self.be
+        xs = _lib.as_f64(target_x, ndim=2)
+        m = len(xs)
+        per = (m + g.world - 1) // g.world
+        lo, hi = min(m, g.rank * per), min(m, (g.rank + 1) * per)
+        part = np.zeros(per)
+        if hi > lo:
+            part[:hi - lo] = be.predict_mean(xs[lo:hi], self.x, self.kernel_terms, self.alpha)
+        if g.world == 1:
+            return part[:m]
+        mine = be.from_numpy(part)
+        parts = [be.zeros(per) for _ in range(g.world)]
+        g.dist.all_gather(parts, mine)
+        return np.concatenate([be.to_numpy(t) for t in parts])[:m]
+
+    def variance(self, target_x):
+        """pointwise posterior variance: V = L^-1 K(x, x*) by the same block-cyclic sweep (queries sharded over
+        process columns, rows of V distributed like the rows of L), then column norms"""
+        g, be, nb = self.g, self.be, self.nb
+        A = self.A
+        xs = _lib.as_f64(target_x, ndim=2)
+        m = len(xs)
+        per = (m + g.Q - 1) // g.Q
+        per = (per + 127) // 128 * 128
+        lo, hi = min(m, g.q * per), min(m, (g.q + 1) * per)
+        gi = self._global_index(self.row_blocks)
+        nvr = int(np.sum(gi < self.n))
+        xr = np.zeros((self.mloc, self.d))
+        xr[:nvr] = self.x[gi[:nvr]]
+        xq = np.zeros((per, self.d))
+        xq[:hi - lo] = xs[lo:hi]
+        V = be.zeros(self.mloc, per)
+        be.cov(xr, xq, self.kernel_terms, V, nvr, hi - lo)
+        for k in range(self.nblk):
+            pk, qk = k % g.P, k % g.Q
+            kr, kc = k // g.P, k // g.Q
+            i0 = self._first_local(self.row_blocks, k)
+            mt = self.mloc - i0 * nb
+            # diagonal block to the whole process row pk, which solves its slice of block row k of V
+            vk = be.zeros(nb, per)
+            if g.p == pk:
+                lkk = be.zeros(nb, nb)
+                if g.q == qk:
+                    lkk.copy_(A[kr * nb:(kr + 1) * nb, kc * nb:(kc + 1) * nb])
+                self._bcast_row(lkk, pk, qk)
+                be.trsm_left(lkk, V[kr * nb:(kr + 1) * nb])
+                vk.copy_(V[kr * nb:(kr + 1) * nb])
+            self._bcast_col(vk, g.q, pk)
+            # panel blocks L[I][k], I > k, along process rows
+            if mt > 0:
+                wrow = be.zeros(mt, nb)
+                if g.q == qk:
+                    wrow.copy_(A[i0 * nb:, kc * nb:(kc + 1) * nb])
+                self._bcast_row(wrow, g.p, qk)
+                be.gemm_nn(V[i0 * nb:], wrow, vk)
+            be.fence()
+        sq = be.colsq(V)
+        if g.P > 1:
+            t = be.from_numpy(sq)
+            g.dist.all_reduce(t, op=g.dist.ReduceOp.SUM, group=g.col_groups[g.q])
+            sq = be.to_numpy(t)
+        var_q = np.zeros(per)
+        if hi > lo:
+            var_q[:hi - lo] = be.prior_diag(xs[lo:hi], self.kernel_terms) - sq[:hi - lo]
+        if g.world == 1:
+            return var_q[:m]
+        mine = be.from_numpy(var_q)
+        parts = [be.zeros(per) for _ in range(g.world)]
+        g.dist.all_gather(parts, mine)
+        # ranks of one process column hold identical slices; take grid row 0
+        out = np.concatenate([be.to_numpy(parts[g.rank_of(0, qq)]) for qq in range(g.Q)])
+        return out[:m]

@@ -1,0 +1,96 @@
+"""The 2-D block-cyclic driver (muses-gaussian-process-interpolator_amd/distributed.py) at world size 2 and 4
+over gloo on CPU, with the numpy tile backend: every rank must reproduce the single-process Cholesky results."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, P, Q, n, d, m, nb, port, seed):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from mgpi_amd.distributed import DistributedGP, ProcessGrid
+        from dist_cpu_backend import NumpyTileBackend
+        from oracle import mgpi_oracle as oracle
+
+        rng = np.random.default_rng(seed)
+        x = rng.random((n, d))
+        f = np.sin(3 * x[:, 0]) + x[:, -1]
+        xs = rng.random((m, d))
+        xs[0] = x[3]                                   # a query on a source
+        ell = tuple(np.full(d, 0.3))
+        kernel = [(0, 1.1, ell), (1, 0.02, ())]        # white noise inside the kernel too
+        nugget = [(1, 0.1, ())]
+        grid = ProcessGrid(dist, P, Q)
+        assert (grid.p, grid.q) == divmod(rank, Q)
+        gp = DistributedGP(grid, NumpyTileBackend(torch), x, kernel, kernel + nugget, nb=nb)
+        gp.build()
+        logdet = gp.factor()
+        alpha = gp.solve(f)
+        mean = gp.mean(xs)
+        var = gp.variance(xs)
+
+        okernel = [oracle.term_se(1.1, *ell), oracle.term_white(0.02)]
+        onugget = [oracle.term_white(0.1)]
+        K = oracle.x2cov(okernel + onugget, x, x)
+        L = np.linalg.cholesky(K)
+        ref_alpha = oracle.solve_cholesky(L, f)
+        ref_mean = oracle.x2cov(okernel, xs, x) @ ref_alpha
+        ref_var = oracle.diag_variance_cholesky(okernel, L, xs, x)
+        assert abs(logdet - 2 * np.sum(np.log(np.diag(L)))) < 1e-10 * max(1.0, abs(logdet)), 'logdet'
+        assert np.max(np.abs(alpha - ref_alpha)) < 1e-9 * np.max(np.abs(ref_alpha)), 'alpha'
+        assert np.max(np.abs(mean - ref_mean)) < 1e-10 * np.max(np.abs(ref_mean)), 'mean'
+        assert np.max(np.abs(var - ref_var)) < 1e-10, 'variance'
+        # every rank holds the same replicated results
+        t = torch.from_numpy(np.concatenate([alpha, mean, var]))
+        lo, hi = t.clone(), t.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi), 'ranks disagree'
+        # a non positive definite matrix is reported on every rank with the same pivot
+        bad = DistributedGP(grid, NumpyTileBackend(torch), np.vstack([x[:5], x[:5]]), [(0, 1.0, ell)], [(0, 1.0, ell)], nb=nb)
+        bad.build()
+        try:
+            bad.factor()
+            raise AssertionError('singular matrix was not detected')
+        except np.linalg.LinAlgError:
+            pass
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,P,Q,n,nb', [
+    (2, 1, 2, 70, 8),      # world size 2: one grid row
+    (2, 2, 1, 70, 8),      # world size 2: one grid column
+    (2, 1, 2, 64, 16),     # N an exact multiple of nb * lcm(P, Q): no padding
+    (4, 2, 2, 150, 16),    # 2 x 2 grid, ragged N
+    (1, 1, 1, 37, 8),      # degenerate grid: the driver without communication
+])
+def test_block_cyclic_gloo(world, P, Q, n, nb):
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(world, P, Q, n, 3, 21, nb, _free_port(), 100 + n), nprocs=world, join=True)
+
+
+def test_choose_grid():
+    import mgpi_amd
+    from mgpi_amd.distributed import choose_grid
+    assert [choose_grid(w) for w in (1, 2, 4, 8, 6)] == [(1, 1), (1, 2), (2, 2), (2, 4), (2, 3)]
