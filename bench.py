@@ -19,9 +19,12 @@ launches, recorded inside the timed region on the stream the kernel runs on; pea
 fp64 matrix, spec).  cpu_baseline = the numpy oracle (a port of the reference's algorithm) on a bounded
 sample of the same recipe, host cores of this box.
 
-N>1: one process per GPU (torch.distributed.run).  Round 1 runs independent replicas of the workload on
-every rank (scaling "weak", no data-path collective); the 2-D block-cyclic Cholesky over RCCL is the next
-row (DESIGN.md section f).
+N>1: one process per GPU (torch.distributed.run, backend nccl = RCCL over xGMI).  ONE GP is factored across
+all ranks by the 2-D block-cyclic right-looking Cholesky of muses-gaussian-process-interpolator_amd/distributed.py
+(P x Q = 1x2, 2x2, 2x4; panel broadcasts along process rows and columns, local trailing updates on fp64 MFMA),
+followed by the distributed solve, mean and variance.  Scaling is "weak" in the O(N^3) work: N = 32768 * G^(1/3)
+rounded to the block grid (40960, 52224, 65536 = BASELINE.json configs[3]); value = whole-job algorithmic
+flops / max-over-ranks wall time.
 """
 import argparse
 import json
@@ -42,6 +45,12 @@ WORKLOADS = {
     'c2': ((32, 16, 16), 3, 4096, 2),
     'c3': ((32, 32, 32), 3, 4096, 3),
 }
+# weak-scaling series for N > 1 GPU: N ~ 32768 * G^(1/3), a multiple of nb * lcm(P, Q)
+MULTI = {
+    2: ((32, 32, 40), 3, 4096, 3),          # N = 40960, grid 1 x 2
+    4: ((32, 34, 48), 3, 4096, 3),          # N = 52224, grid 2 x 2
+    8: ((16, 16, 16, 16), 4, 4096, 4),      # N = 65536, D = 4, grid 2 x 4  (BASELINE.json configs[3] = C4)
+}
 
 
 def make_inputs(n_side, m, seed):
@@ -50,7 +59,7 @@ def make_inputs(n_side, m, seed):
     axes = [(np.arange(s) + 0.5) / s for s in n_side]
     x = np.transpose([a.ravel() for a in np.meshgrid(*axes, indexing='ij')])
     x = x + rng.uniform(-0.1, 0.1, x.shape) / np.array(n_side)
-    f = np.sin(3 * x[:, 0]) * np.cos(2 * x[:, 1]) + 0.5 * np.sin(4 * x[:, 2])
+    f = np.sin(3 * x[:, 0]) * np.cos(2 * x[:, 1]) + 0.5 * np.sin(4 * x[:, -1])
     xs = rng.random((m, len(n_side)))
     ell = tuple(2.0 / np.array(n_side, dtype=float))
     return x, f, xs, ell
@@ -103,11 +112,36 @@ class GpuStep(object):
                                    self.var.handle))
 
 
+class DistributedStep(object):
+    """one GP across all ranks: block-cyclic build + factor + solve + mean + variance (inputs replicated on the
+    hosts, K / L / V distributed in HBM)"""
+
+    def __init__(self, torch, dist, x, f, xs, ell):
+        import mgpi_amd as mgpi
+        from mgpi_amd.distributed import DistributedGP, HipTileBackend, ProcessGrid
+        self.ctx = mgpi.default_context()
+        self.grid = ProcessGrid(dist)
+        self.be = HipTileBackend(torch, self.ctx)
+        k = mgpi.SquaredExponentialKernel(1.0, *ell)
+        nug = mgpi.WhiteNoiseKernel(1e-2)
+        self.gp = DistributedGP(self.grid, self.be, x, k.terms(), (k + nug).terms(), nb=NB)
+        self.f, self.xs = f, xs
+        self.n, self.m = len(x), len(xs)
+
+    def run(self):
+        gp = self.gp
+        gp.build()
+        gp.factor()
+        gp.solve(self.f)
+        self.mean = gp.mean(self.xs)
+        self.var = gp.variance(self.xs)
+
+
 def cpu_baseline(seed=7):
     """numpy oracle ("port" of the reference algorithm: pair materialisation + LU inverse) on a bounded sample:
-    the same recipe at N=4096 (16x16x16 grid), M=512, one condition() = mean + full covariance"""
+    the same recipe at N=8192 (16x16x32 grid), M=512, one condition() = mean + full covariance"""
     from oracle import mgpi_oracle as oracle
-    n_side, m = (16, 16, 16), 512
+    n_side, m = (16, 16, 32), 512
     x, f, xs, ell = make_inputs(n_side, m, seed)
     kernel, nugget = [oracle.term_se(1.0, *ell)], [oracle.term_white(1e-2)]
     t0 = time.perf_counter()
@@ -146,21 +180,35 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    # developer switch: run the multi-GPU code path on a 1 x 1 grid (one GPU) to exercise its plumbing
+    force_dist = world == 1 and os.environ.get('MGPI_BENCH_FORCE_DIST') == '1'
+    distributed = world > 1 or force_dist
+    if distributed:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
-    n_side, d, m, seed = WORKLOADS[args.workload]
-    x, f, xs, ell = make_inputs(n_side, m, seed + 100 * rank)
+    if not distributed:
+        n_side, d, m, seed = WORKLOADS[args.workload]
+        x, f, xs, ell = make_inputs(n_side, m, seed)
+        step = GpuStep(x, f, xs, ell)
+        name, par = args.workload.upper(), 'single GPU'
+    else:
+        assert force_dist or world in MULTI, 'supported GPU counts: 1, %s' % sorted(MULTI)
+        n_side, d, m, seed = MULTI[2 if force_dist else world]
+        x, f, xs, ell = make_inputs(n_side, m, seed)           # the same seed on every rank: replicated inputs
+        step = DistributedStep(torch, dist, x, f, xs, ell)
+        name = 'C4' if world == 8 else 'C3 scaled by %d^(1/3)' % world
+        par = '2-D block-cyclic %dx%d, nb=%d, RCCL panel broadcasts' % (step.grid.P, step.grid.Q, NB)
     n = len(x)
-    step = GpuStep(x, f, xs, ell)
     ctx = step.ctx
 
     def fence():
         ctx.sync()
-        if world > 1:
+        if distributed:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -185,30 +233,34 @@ def main():
     ctx.set_profile(False)
 
     if rank == 0:
-        flops = step_flops(n, m) * world
+        flops = step_flops(n, m)                                  # one GP of size n, whatever the GPU count
         value = flops * args.steps / elapsed / 1e12
-        tflops_syrk = trailing_flops(n) * args.steps / (syrk_ms * 1e-3) / 1e12
+        if not distributed:
+            tr_flops = trailing_flops(n)
+        else:
+            tr_flops = step.gp.trailing_flops / (args.steps + args.warmup)      # this rank's share, per step
+        tflops_syrk = tr_flops * args.steps / (syrk_ms * 1e-3) / 1e12
         out = {
             'metric': 'condition+predict achieved fp64 TFLOP/s (wall-clock in ms_per_step) at N training points',
             'value': value, 'unit': 'TFLOP/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': '%s: N=%d D=%d jittered grid, SquaredExponential + WhiteNoise nugget, blocked '
-                                   'Cholesky nb=%d, M=%d queries (mean+variance); per GPU%s'
-                                   % (args.workload.upper(), n, d, NB, m, '' if world == 1 else ', independent replicas'),
-                       'N': n, 'D': d, 'M': m, 'nb': NB, 'parallelism': 'replicas%d' % world},
+                                   'Cholesky nb=%d, M=%d queries (mean+variance)' % (name, n, d, NB, m),
+                       'N': n, 'D': d, 'M': m, 'nb': NB, 'parallelism': par},
             'roofline': {'bound': 'mfma', 'achieved': tflops_syrk, 'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': tflops_syrk / PEAK_FP64_MFMA_TFLOPS, 'traffic': load_traffic(args.workload),
-                         'kernel': 'gemm_f64_kernel<128,128,NT,lower> (Cholesky trailing update, syrk)',
+                         'frac': tflops_syrk / PEAK_FP64_MFMA_TFLOPS,
+                         'traffic': load_traffic(args.workload) if not distributed else None,
+                         'kernel': 'gemm_f64_kernel<128,128,NT%s> (Cholesky trailing update%s)' % ((',lower', ', syrk') if not distributed else ('', ', rank 0 local blocks')),
                          'launches': int(syrk_launches), 'avg_launch_ms': syrk_ms / max(1, syrk_launches),
-                         'algorithmic_flops_per_step': trailing_flops(n)},
+                         'algorithmic_flops_per_step': tr_flops},
             'stages_ms_per_step': {'potrf': potrf_ms / args.steps, 'potrf_trailing_update': syrk_ms / args.steps,
                                    'potrf_panels': panel_ms / args.steps},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

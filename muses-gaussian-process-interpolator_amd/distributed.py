@@ -244,6 +244,7 @@ class DistributedGP(object):
         self.A = None
         self.logdet = None
         self.alpha = None
+        self.trailing_flops = 0.0     # algorithmic flops of this rank's trailing updates (bench.py roofline)
 
     # -- index helpers ------------------------------------------------------------------------------------
     def _global_index(self, blocks):
@@ -253,31 +254,24 @@ class DistributedGP(object):
         """number of local blocks with global index <= bound"""
         return int(np.searchsorted(np.asarray(blocks), bound, side='right'))
 
-    # -- communication (fenced on both sides: tile kernels run on our stream, collectives on torch's) ---------
+    # -- communication ------------------------------------------------------------------------------------
+    # No host synchronisation: with the HIP backend our stream IS torch's current stream, a (non-async) NCCL
+    # collective waits for the current stream's earlier work and the current stream then waits for the
+    # collective; gloo collectives are synchronous on the host.
     def _bcast_row(self, t, p, src_q):
-        self.be.fence()
         self.g.bcast_row(t, p, src_q)
-        self.be.fence()
 
     def _bcast_col(self, t, q, src_p):
-        self.be.fence()
         self.g.bcast_col(t, q, src_p)
-        self.be.fence()
 
     def _bcast_world(self, t, src):
-        self.be.fence()
         self.g.bcast_world(t, src)
-        self.be.fence()
 
     def _reduce_row(self, t, p, dst_q):
-        self.be.fence()
         self.g.reduce_row(t, p, dst_q)
-        self.be.fence()
 
     def _reduce_col(self, t, q, dst_p):
-        self.be.fence()
         self.g.reduce_col(t, q, dst_p)
-        self.be.fence()
 
     # -- build --------------------------------------------------------------------------------------------
     def build(self):
@@ -290,7 +284,8 @@ class DistributedGP(object):
         xc = np.zeros((self.nloc, self.d))
         xr[:nvr] = self.x[gi[:nvr]]
         xc[:nvc] = self.x[gj[:nvc]]
-        self.A = be.zeros(self.mloc, self.nloc)
+        if self.A is None:
+            self.A = be.zeros(self.mloc, self.nloc)        # every entry is (re)written by the tile build below
         be.cov(xr, xc, self.solve_terms, self.A, nvr, nvc)
         # padded global indices (>= n) get a unit diagonal so the padded matrix stays positive definite
         for li, I in enumerate(self.row_blocks):
@@ -356,7 +351,9 @@ class DistributedGP(object):
                     if il >= len(self.row_blocks):
                         continue
                     be.gemm_nt(A[il * nb:, jl * nb:(jl + 1) * nb], wrow[(il - i0) * nb:], wcol[(jl - j0) * nb:(jl - j0 + 1) * nb])
-            be.fence()
+                    rows = self.mloc - il * nb
+                    diag = nb if self.row_blocks[il] == J else 0          # a diagonal block counts as its lower half
+                    self.trailing_flops += 2.0 * (rows - diag) * nb * nb + diag * (nb + 1.0) * nb
         # logdet and the first failing pivot, agreed by everyone
         if g.world > 1:
             s = self.be.from_numpy(np.array([logdiag]))
@@ -392,9 +389,7 @@ class DistributedGP(object):
                 if g.q == qk:
                     yk = y[k * nb:(k + 1) * nb]
                     yk.add_(s)
-                    be.fence()
                     be.trsv(A[kr * nb:(kr + 1) * nb, kc * nb:(kc + 1) * nb], yk, 0)
-                    be.fence()
             yk = y[k * nb:(k + 1) * nb]
             self._bcast_world(yk, g.rank_of(pk, qk))
             if g.q == qk:
@@ -413,9 +408,7 @@ class DistributedGP(object):
                 if g.p == pk:
                     xk = y[k * nb:(k + 1) * nb]
                     xk.add_(s)
-                    be.fence()
                     be.trsv(A[kr * nb:(kr + 1) * nb, kc * nb:(kc + 1) * nb], xk, 1)
-                    be.fence()
             xk = y[k * nb:(k + 1) * nb]
             self._bcast_world(xk, g.rank_of(pk, qk))
             if g.p == pk:
@@ -481,7 +474,6 @@ class DistributedGP(object):
                     wrow.copy_(A[i0 * nb:, kc * nb:(kc + 1) * nb])
                 self._bcast_row(wrow, g.p, qk)
                 be.gemm_nn(V[i0 * nb:], wrow, vk)
-            be.fence()
         sq = be.colsq(V)
         if g.P > 1:
             t = be.from_numpy(sq)
