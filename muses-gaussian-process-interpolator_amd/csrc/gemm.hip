@@ -65,6 +65,34 @@ __device__ __forceinline__ void tile_store(double* __restrict__ lds, int tid,
     }
 }
 
+// global -> LDS directly (global_load_lds_dwordx4, no staging registers, no ds_write): the LDS destination of
+// a wave instruction is wave-uniform base + lane*16, i.e. linear, so the image's swizzle is applied to the
+// per-lane SOURCE address instead (cdna_hip_programming.md 5.4 rule 21).  BT = 128 only: one wave instruction
+// (1 KiB) then covers 8 whole swizzled rows of a row-major image, or one whole k-row of a k-major image.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+template <bool KMAJOR>
+__device__ __forceinline__ void tile_glds(const double* __restrict__ g, int64_t ld, int64_t t0, int64_t k0, int tid,
+                                          double* __restrict__ lds) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int idx = tid + 256 * s;
+        const double* src;
+        double* dst;                                   // wave-uniform: where lane 0 of this wave lands
+        if (KMAJOR) {                                  // idx -> k-row idx/64, lane covers columns 2*(idx%64)..+1
+            const int kr = idx >> 6, c2 = idx & 63;
+            src = g + (k0 + kr) * ld + t0 + 2 * c2;
+            dst = lds + (4 * s + wave) * (128 + 16);
+        } else {                                       // idx -> row idx/8, physical chunk idx%8 holds logical chunk p^f(row)
+            const int row = idx >> 3, p = idx & 7;
+            src = g + (t0 + row) * ld + k0 + 2 * (p ^ ((row >> 1) & 7));
+            dst = lds + (32 * s + 8 * wave) * GEMM_SR;
+        }
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+    }
+}
+
 // fragments of one half stage (h = 0, 1 -> k in [8h, 8h+8)) for the tile row/column t: f[0] feeds the first MFMA
 // of the pair (k = 8h + 2g), f[1] the second (k = 8h + 2g + 1); g = lane >> 4
 template <int BT, bool KMAJOR>
@@ -131,7 +159,7 @@ __device__ __forceinline__ void tile_decode(int64_t idx, int tm, int tn, int& ti
     }
 }
 
-template <int BM, int BN, bool AK, bool BKM, bool LOWER>
+template <int BM, int BN, bool AK, bool BKM, bool LOWER, bool GLDS = false>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(int64_t k, const double* __restrict__ A, int64_t lda,
                                                           const double* __restrict__ B, int64_t ldb,
                                                           double* __restrict__ C, int64_t ldc, int tiles_m,
@@ -159,8 +187,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(int64_t k, const doubl
     const int fr = lane & 15, fq = lane >> 4;
 
     double2 ra[GA::vecs], rb[GB::vecs];
-    tile_load<BM, AK>(A, lda, m0, 0, tid, ra);
-    tile_load<BN, BKM>(B, ldb, n0, 0, tid, rb);
+    if constexpr (GLDS) {
+        tile_glds<AK>(A, lda, m0, 0, tid, lds);
+        tile_glds<BKM>(B, ldb, n0, 0, tid, lds + GA::doubles);
+    } else {
+        tile_load<BM, AK>(A, lda, m0, 0, tid, ra);
+        tile_load<BN, BKM>(B, ldb, n0, 0, tid, rb);
+    }
 
     // The accumulators start from the C tile and the MFMAs add (-A) B: the result C - A B is then stored straight
     // from the accumulators.  (An epilogue that re-read C cost one exposed HBM round trip per tile.)
@@ -173,8 +206,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(int64_t k, const doubl
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 acc[i][j][r] = C[(m0 + wr * WM + i * 16 + fq + 4 * r) * ldc + n0 + wc * WN + j * 16 + fr];
-    tile_store<BM, AK>(lds, tid, ra);
-    tile_store<BN, BKM>(lds + GA::doubles, tid, rb);
+    if constexpr (!GLDS) {
+        tile_store<BM, AK>(lds, tid, ra);
+        tile_store<BN, BKM>(lds + GA::doubles, tid, rb);
+    }
     __syncthreads();
 
     // one LDS stage = 2 half stages x 2 MFMA k-steps on the wave's FM x FN accumulator tiles
@@ -204,14 +239,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(int64_t k, const doubl
     for (int64_t kt = 0; kt + 1 < nk; ++kt) {
         const int cur = (int)(kt & 1);
         // issue the next stage's HBM/L2 loads; they land while the MFMAs below run
-        tile_load<BM, AK>(A, lda, m0, (kt + 1) * GEMM_BK, tid, ra);
-        tile_load<BN, BKM>(B, ldb, n0, (kt + 1) * GEMM_BK, tid, rb);
-        compute_stage(lds + cur * STAGE, lds + cur * STAGE + GA::doubles);
-        // keep the staging writes (and the vmcnt waits in front of them) behind the stage's MFMAs: the loads then
-        // have the whole stage (64 MFMAs = 4096 cycles) to land
-        __builtin_amdgcn_sched_barrier(0);
-        tile_store<BM, AK>(lds + (cur ^ 1) * STAGE, tid, ra);
-        tile_store<BN, BKM>(lds + (cur ^ 1) * STAGE + GA::doubles, tid, rb);
+        if constexpr (GLDS) {
+            tile_glds<AK>(A, lda, m0, (kt + 1) * GEMM_BK, tid, lds + (cur ^ 1) * STAGE);
+            tile_glds<BKM>(B, ldb, n0, (kt + 1) * GEMM_BK, tid, lds + (cur ^ 1) * STAGE + GA::doubles);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_stage(lds + cur * STAGE, lds + cur * STAGE + GA::doubles);
+        } else {
+            tile_load<BM, AK>(A, lda, m0, (kt + 1) * GEMM_BK, tid, ra);
+            tile_load<BN, BKM>(B, ldb, n0, (kt + 1) * GEMM_BK, tid, rb);
+            compute_stage(lds + cur * STAGE, lds + cur * STAGE + GA::doubles);
+            // keep the staging writes (and the vmcnt waits in front of them) behind the stage's MFMAs: the loads
+            // then have the whole stage (64 MFMAs = 4096 cycles) to land
+            __builtin_amdgcn_sched_barrier(0);
+            tile_store<BM, AK>(lds + (cur ^ 1) * STAGE, tid, ra);
+            tile_store<BN, BKM>(lds + (cur ^ 1) * STAGE + GA::doubles, tid, rb);
+        }
         __syncthreads();
     }
     {
@@ -229,16 +271,151 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(int64_t k, const doubl
                 C[(m0 + wr * WM + i * 16 + fq + 4 * r) * ldc + n0 + wc * WN + j * 16 + fr] = acc[i][j][r];
 }
 
-template <int BM, int BN, bool AK, bool BKM, bool LOWER>
+// ---- ping-pong variant: two 4-wave groups per 512-thread workgroup, one workgroup per CU ----------------------
+// Each group owns one 128x128 tile (its own LDS double buffer, its own accumulators) and runs the loop above,
+// but the groups are staggered by one barrier: every K-stage has two workgroup barriers, and between two
+// barriers one group issues its 64 MFMAs per wave while the other does everything that is NOT matrix work
+// (wait for its global loads, write the next stage to LDS).  Each SIMD hosts one wave of either group, so its
+// MFMA pipe always has exactly one wave feeding it and the LDS/global phases of one group hide under the MFMA
+// phase of the other - with two independent workgroups per CU the two fell into lockstep and stalled together
+// (measured: loop at 83-87 % of MFMA issue rate).
+template <bool AK, bool BKM, bool LOWER>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(int64_t k, const double* __restrict__ A, int64_t lda,
+                                                         const double* __restrict__ B, int64_t ldb,
+                                                         double* __restrict__ C, int64_t ldc, int tiles_m, int tiles_n,
+                                                         int64_t ntiles) {
+    constexpr int BM = 128, BN = 128, WM = 64, WN = 64, FM = 4, FN = 4;
+    using GA = TileGeom<BM, AK>;
+    using GB = TileGeom<BN, BKM>;
+    constexpr int STAGE = GA::doubles + GB::doubles;
+    __shared__ __attribute__((aligned(16))) double lds_all[2][2 * STAGE];
+
+    const int group = threadIdx.x >> 8;          // 0: waves 0-3, 1: waves 4-7
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    double* lds = lds_all[group];
+
+    const int64_t nwg = (ntiles + 1) / 2;
+    int64_t wg = blockIdx.x;
+    {
+        const int64_t q = nwg / 8, r = nwg % 8, xcd = wg % 8, loc = wg / 8;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int64_t tile = 2 * wg + group;
+    // an odd tile count leaves the very last group without a tile: it recomputes the last tile and skips the
+    // store, so that every wave runs the same straight-line loop (no predication around loads or barriers)
+    const bool live = tile < ntiles;
+    int ti, tj;
+    tile_decode<LOWER>(live ? tile : ntiles - 1, tiles_m, tiles_n, ti, tj);
+    const int64_t m0 = (int64_t)ti * BM, n0 = (int64_t)tj * BN;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int64_t nk = k / GEMM_BK;
+
+    tile_glds<AK>(A, lda, m0, 0, tid, lds);
+    tile_glds<BKM>(B, ldb, n0, 0, tid, lds + GA::doubles);
+    double4_t acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[i][j][r] = C[(m0 + wr * WM + i * 16 + fq + 4 * r) * ldc + n0 + wc * WN + j * 16 + fr];
+    __syncthreads();                              // stage 0 visible (both groups)
+    if (group == 1) __syncthreads();              // the stagger: group 1 runs one barrier behind (pairs with B1 of group 0)
+
+    // half a stage at a time (8 ds_read_b128 = 32 VGPRs of fragments live), fenced so that hipcc keeps the
+    // order loads | reads+MFMAs | barrier | staging writes: left alone it waited for every global load right
+    // after issuing it and parked the data in scratch
+    auto compute_stage = [&](const double* __restrict__ la, const double* __restrict__ lb) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double af[FM][2], bf[FN][2];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                frag_pair<BM, AK>(la, wr * WM + i * 16 + fr, h, fq, af[i]);
+                af[i][0] = -af[i][0];
+                af[i][1] = -af[i][1];
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) frag_pair<BN, BKM>(lb, wc * WN + j * 16 + fr, h, fq, bf[j]);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][s2], bf[j][s2], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    for (int64_t kt = 0; kt + 1 < nk; ++kt) {
+        const int cur = (int)(kt & 1);
+        // ---- matrix phase of this group (the other group idles between its two barriers): the LDS-DMA loads of the
+        // next stage fly into the other buffer while the 64 MFMAs per wave run
+        tile_glds<AK>(A, lda, m0, (kt + 1) * GEMM_BK, tid, lds + (cur ^ 1) * STAGE);
+        tile_glds<BKM>(B, ldb, n0, (kt + 1) * GEMM_BK, tid, lds + (cur ^ 1) * STAGE + GA::doubles);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_stage(lds + cur * STAGE, lds + cur * STAGE + GA::doubles);
+        __syncthreads();                          // B1: every wave has waited for its own loads (vmcnt(0)) -> stage kt+1 visible
+        __syncthreads();                          // B2: hands the MFMA pipe back (the other group computes between B1 and B2)
+    }
+    {
+        const int cur = (int)((nk - 1) & 1);
+        compute_stage(lds + cur * STAGE, lds + cur * STAGE + GA::doubles);
+    }
+    if (group == 0) __syncthreads();              // matches group 1's stagger barrier: equal barrier counts
+
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    C[(m0 + wr * WM + i * 16 + fq + 4 * r) * ldc + n0 + wc * WN + j * 16 + fr] = acc[i][j][r];
+    }
+}
+
+template <bool AK, bool BKM, bool LOWER>
+static int launch_pp(mgpi_ctx* ctx, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, const double* B,
+                     int64_t ldb, double* C, int64_t ldc) {
+    const int64_t tm = m / 128, tn = n / 128;
+    const int64_t ntiles = LOWER ? tm * (tm + 1) / 2 : tm * tn;
+    const int64_t nwg = (ntiles + 1) / 2;
+    MGPI_REQUIRE(nwg > 0 && nwg < (int64_t)2147483647, "gemm: tile count %lld out of range", (long long)ntiles);
+    hipLaunchKernelGGL((gemm_pp_kernel<AK, BKM, LOWER>), dim3((unsigned)nwg), dim3(512), 0, ctx->stream, k, A, lda, B, ldb, C,
+                       ldc, (int)tm, (int)tn, ntiles);
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int BM, int BN, bool AK, bool BKM, bool LOWER, bool GLDS = false>
 static int launch_one(mgpi_ctx* ctx, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, const double* B,
                       int64_t ldb, double* C, int64_t ldc) {
     const int64_t tm = m / BM, tn = n / BN;
     const int64_t ntiles = LOWER ? tm * (tm + 1) / 2 : tm * tn;
     MGPI_REQUIRE(ntiles > 0 && ntiles < (int64_t)2147483647, "gemm: tile count %lld out of range", (long long)ntiles);
-    hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, AK, BKM, LOWER>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, k,
+    hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, AK, BKM, LOWER, GLDS>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, k,
                        A, lda, B, ldb, C, ldc, (int)tm, (int)tn, ntiles);
     MGPI_HIP_TRY(hipGetLastError());
     return 0;
+}
+
+// the ping-pong kernel is a MEASURED VARIANT, off by default: strict alternation of two 4-wave groups reached
+// 53.5 TFLOP/s at n=32256 against 61.3 for two independent workgroups per CU (whose prologue/epilogue overlap
+// the other workgroup's main loop).  MGPI_GEMM_PP=1 selects it (developer switch, tested).
+static bool use_pp(int64_t ntiles) {
+    static const char* env = getenv("MGPI_GEMM_PP");
+    (void)ntiles;
+    return env ? atoi(env) != 0 : false;
+}
+// direct-to-LDS staging for the 128x128 tiles: +4 % on the trailing update (61.3 vs 58.8 TFLOP/s at n=32256);
+// MGPI_GEMM_GLDS=0 selects the register-staged form (developer switch, both forms are tested)
+static bool use_glds() {
+    static const char* env = getenv("MGPI_GEMM_GLDS");
+    return env ? atoi(env) != 0 : true;
 }
 
 template <bool AK, bool BKM>
@@ -247,9 +424,15 @@ static int launch_shape(mgpi_ctx* ctx, int lower_only, int64_t m, int64_t n, int
     if (lower_only) {
         MGPI_REQUIRE(m == n && m % 128 == 0, "gemm(lower): needs m == n, multiple of 128 (got %lld x %lld)", (long long)m,
                      (long long)n);
+        if (use_pp(m / 128 * (m / 128 + 1) / 2)) return launch_pp<AK, BKM, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
+        if (use_glds()) return launch_one<128, 128, AK, BKM, true, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
         return launch_one<128, 128, AK, BKM, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
     }
-    if (m % 128 == 0 && n % 128 == 0) return launch_one<128, 128, AK, BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
+    if (m % 128 == 0 && n % 128 == 0) {
+        if (use_pp((m / 128) * (n / 128))) return launch_pp<AK, BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
+        if (use_glds()) return launch_one<128, 128, AK, BKM, false, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
+        return launch_one<128, 128, AK, BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
+    }
     if (m % 128 == 0) return launch_one<128, 64, AK, BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
     if (n % 128 == 0) return launch_one<64, 128, AK, BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
     return launch_one<64, 64, AK, BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
