@@ -158,6 +158,10 @@ int  mgpi_cov_block_dev(mgpi_ctx* ctx, const mgpi_mat* X1, int64_t n1_valid, con
                         const mgpi_kernel_desc* terms, int nterms, mgpi_mat* out);
 /* C (m x n) -= A (m x k) * B (k x n)   (row-major B: the update of the multi-rhs triangular solve) */
 int  mgpi_gemm_nn_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* B, mgpi_mat* C);
+/* C -= A B^T restricted to the tiles on/below the GLOBAL diagonal of a 2-D block-cyclic matrix: C = this rank's local
+ * trailing matrix starting at local block (bi0, bj0) of an nb-blocked matrix on a P x Q grid, this rank at (p, q) */
+int  mgpi_gemm_nt_stair_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* B, mgpi_mat* C, int P, int p, int Q, int q,
+                            int bi0, int bj0, int nb);
 /* A <- A L^-T : panel trsm with a factored diagonal block L (w x w) on a block of rows A (m x w) */
 int  mgpi_trsm_right_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* A);
 /* single-vector half-solve with a factored diagonal block (<= 4096 rows): L y = b (trans=0) / L^T x = b (trans=1) */

@@ -159,11 +159,23 @@ __device__ __forceinline__ void tile_decode(int64_t idx, int tm, int tn, int& ti
     }
 }
 
+// block-cyclic "staircase": which tiles of a rank's LOCAL trailing matrix lie on or below the GLOBAL diagonal.
+// Local tile (ti, tj) belongs to global block row p + P*(bi0 + ti/tpb) and block column q + Q*(bj0 + tj/tpb).
+// Only the (almost entirely) live part is enumerated: per band of GEMM_BAND tile rows the columns up to the last one
+// that band's bottom row reaches; prefix[b] = number of enumerated tiles before band b.  (Enumerating the full
+// rectangle and letting dead tiles exit left the XCD that got the top bands idle: 1.9x slower.)
+#define GEMM_STAIR_BANDS 64
+struct gemm_stair {
+    int on, P, p, Q, q, bi0, bj0, tpb;
+    int nbands;
+    int prefix[GEMM_STAIR_BANDS + 1];
+};
+
 template <int BM, int BN, bool AK, bool BKM, bool LOWER, bool GLDS = false>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(int64_t k, const double* __restrict__ A, int64_t lda,
                                                           const double* __restrict__ B, int64_t ldb,
                                                           double* __restrict__ C, int64_t ldc, int tiles_m,
-                                                          int tiles_n, int64_t ntiles) {
+                                                          int tiles_n, int64_t ntiles, gemm_stair st) {
     constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
     constexpr int FM = WM / 16, FN = WN / 16;   // MFMA tiles per wave
     using GA = TileGeom<BM, AK>;
@@ -179,7 +191,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(int64_t k, const doubl
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
     int ti, tj;
-    tile_decode<LOWER>(bid, tiles_m, tiles_n, ti, tj);
+    if (!LOWER && st.on) {   // multi-GPU trailing update: tiles strictly above the global diagonal are not touched
+        int band = 0;
+        while (band + 1 < st.nbands && st.prefix[band + 1] <= bid) ++band;
+        const int within = (int)bid - st.prefix[band];
+        const int rows = (tiles_m - band * GEMM_BAND < GEMM_BAND) ? (tiles_m - band * GEMM_BAND) : GEMM_BAND;
+        tj = within / rows;
+        ti = band * GEMM_BAND + within - tj * rows;
+        const int I = st.p + st.P * (st.bi0 + ti / st.tpb), J = st.q + st.Q * (st.bj0 + tj / st.tpb);
+        if (I < J || (I == J && (ti % st.tpb) < (tj % st.tpb))) return;
+    } else {
+        tile_decode<LOWER>(bid, tiles_m, tiles_n, ti, tj);
+    }
     const int64_t m0 = (int64_t)ti * BM, n0 = (int64_t)tj * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -391,14 +414,21 @@ static int launch_pp(mgpi_ctx* ctx, int64_t m, int64_t n, int64_t k, const doubl
     return 0;
 }
 
+static gemm_stair no_stair() {
+    gemm_stair st;
+    memset(&st, 0, sizeof(st));
+    st.P = st.Q = st.tpb = 1;
+    return st;
+}
+
 template <int BM, int BN, bool AK, bool BKM, bool LOWER, bool GLDS = false>
 static int launch_one(mgpi_ctx* ctx, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, const double* B,
-                      int64_t ldb, double* C, int64_t ldc) {
+                      int64_t ldb, double* C, int64_t ldc, gemm_stair st = no_stair()) {
     const int64_t tm = m / BM, tn = n / BN;
-    const int64_t ntiles = LOWER ? tm * (tm + 1) / 2 : tm * tn;
+    const int64_t ntiles = LOWER ? tm * (tm + 1) / 2 : (st.on ? (int64_t)st.prefix[st.nbands] : tm * tn);
     MGPI_REQUIRE(ntiles > 0 && ntiles < (int64_t)2147483647, "gemm: tile count %lld out of range", (long long)ntiles);
     hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, AK, BKM, LOWER, GLDS>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, k,
-                       A, lda, B, ldb, C, ldc, (int)tm, (int)tn, ntiles);
+                       A, lda, B, ldb, C, ldc, (int)tm, (int)tn, ntiles, st);
     MGPI_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -480,4 +510,40 @@ extern "C" int mgpi_gemm_nn_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat
     const int64_t k = A->pcols < B->prows ? A->pcols : B->prows;
     MGPI_REQUIRE(A->prows >= m && B->pcols >= n, "mgpi_gemm_nn_dev: operand padding smaller than the result's");
     return mgpi_launch_gemm(ctx, 0, 1, 0, m, n, k, A->d, A->ld, B->d, B->ld, C->d, C->ld);
+}
+
+// C -= A B^T restricted to the tiles on/below the GLOBAL diagonal of a 2-D block-cyclic matrix: C is this rank's
+// local trailing matrix (local block rows bi0.., local block columns bj0.. of an nb-blocked matrix on a P x Q grid,
+// this rank at (p, q)), A (m x k) the row panel, B (n x k) the column panel.  One launch per block step.
+extern "C" int mgpi_gemm_nt_stair_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* B, mgpi_mat* C, int P, int p, int Q,
+                                      int q, int bi0, int bj0, int nb) {
+    MGPI_REQUIRE(ctx && A && B && C, "mgpi_gemm_nt_stair_dev: null pointer");
+    MGPI_REQUIRE(A->cols == B->cols && C->rows == A->rows && C->cols == B->rows, "mgpi_gemm_nt_stair_dev: shapes do not conform");
+    MGPI_REQUIRE(P >= 1 && Q >= 1 && p >= 0 && p < P && q >= 0 && q < Q && nb >= 128 && nb % 128 == 0,
+                 "mgpi_gemm_nt_stair_dev: bad grid description");
+    const int64_t m = C->prows, n = C->pcols, k = A->pcols < B->pcols ? A->pcols : B->pcols;
+    MGPI_REQUIRE(m % 128 == 0 && n % 128 == 0 && k % GEMM_BK == 0, "mgpi_gemm_nt_stair_dev: extents must be tile multiples");
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    gemm_stair st = no_stair();
+    st.on = 1; st.P = P; st.p = p; st.Q = Q; st.q = q; st.bi0 = bi0; st.bj0 = bj0; st.tpb = nb / 128;
+    const int tm = (int)(m / 128), tn = (int)(n / 128), tpb = st.tpb;
+    st.nbands = (tm + GEMM_BAND - 1) / GEMM_BAND;
+    MGPI_REQUIRE(st.nbands <= GEMM_STAIR_BANDS, "mgpi_gemm_nt_stair_dev: local trailing matrix has too many tile rows (%d)", tm);
+    int64_t total = 0;
+    for (int b = 0; b < st.nbands; ++b) {
+        st.prefix[b] = (int)total;
+        const int rows = (tm - b * GEMM_BAND < GEMM_BAND) ? (tm - b * GEMM_BAND) : GEMM_BAND;
+        const int last = b * GEMM_BAND + rows - 1;
+        const int64_t gr = (int64_t)(p + P * (bi0 + last / tpb)) * tpb + last % tpb;      // global tile row of the band's bottom row
+        int cmax = 0;                                                                        // columns it reaches
+        while (cmax < tn && (int64_t)(q + Q * (bj0 + cmax / tpb)) * tpb + cmax % tpb <= gr) ++cmax;
+        total += (int64_t)rows * cmax;
+    }
+    st.prefix[st.nbands] = (int)total;
+    if (total == 0) return 0;
+    mgpi_prof_begin(ctx, 0);
+    int rc = use_glds() ? launch_one<128, 128, false, false, false, true>(ctx, m, n, k, A->d, A->ld, B->d, B->ld, C->d, C->ld, st)
+                        : launch_one<128, 128, false, false, false, false>(ctx, m, n, k, A->d, A->ld, B->d, B->ld, C->d, C->ld, st);
+    mgpi_prof_end(ctx, 0);
+    return rc;
 }

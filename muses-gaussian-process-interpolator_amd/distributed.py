@@ -100,6 +100,11 @@ class HipTileBackend(object):
         shape = (rows,) if cols is None else (rows, cols)
         return self.torch.zeros(shape, dtype=self.torch.float64, device=self.device)
 
+    def empty(self, rows, cols=None):
+        """uninitialised buffer: for panels that are fully overwritten by a copy or a broadcast"""
+        shape = (rows,) if cols is None else (rows, cols)
+        return self.torch.empty(shape, dtype=self.torch.float64, device=self.device)
+
     def from_numpy(self, a):
         return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
 
@@ -167,6 +172,14 @@ class HipTileBackend(object):
         hc, ha, hb = self._wrap(c), self._wrap(a), self._wrap(b)
         try:
             _lib.check(self.lib.mgpi_gemm_nt_dev(self.ctx.handle, ha, hb, hc, 0))
+        finally:
+            self._free(hc, ha, hb)
+
+    def gemm_nt_stair(self, c, a, b, P, p, Q, q, bi0, bj0, nb):
+        """the whole local trailing update of one block step in ONE launch: tiles above the global diagonal exit"""
+        hc, ha, hb = self._wrap(c), self._wrap(a), self._wrap(b)
+        try:
+            _lib.check(self.lib.mgpi_gemm_nt_stair_dev(self.ctx.handle, ha, hb, hc, P, p, Q, q, bi0, bj0, nb))
         finally:
             self._free(hc, ha, hb)
 
@@ -309,7 +322,7 @@ class DistributedGP(object):
             mt = self.mloc - i0 * nb                         # local trailing rows
             nt = self.nloc - j0 * nb
             # 1. diagonal block
-            lkk = be.zeros(nb, nb)
+            lkk = be.empty(nb, nb)
             if g.q == qk:
                 if g.p == pk:
                     blk = A[kr * nb:(kr + 1) * nb, kc * nb:(kc + 1) * nb]
@@ -323,37 +336,45 @@ class DistributedGP(object):
                 if mt > 0:
                     be.trsm_right(lkk, A[i0 * nb:, kc * nb:(kc + 1) * nb])
             # 3. panel along process rows
-            wrow = be.zeros(max(mt, 1), nb)
+            wrow = be.empty(max(mt, 1), nb)
             if mt > 0:
                 if g.q == qk:
                     wrow.copy_(A[i0 * nb:, kc * nb:(kc + 1) * nb])
                 self._bcast_row(wrow, g.p, qk)
-            # 4. transposed role along process columns: rank (pr, q) holds L[J][k] for J = q mod Q, J = pr mod P
-            wcol = be.zeros(max(nt, 1), nb)
+            # 4. transposed role along process columns.  The blocks L[J][k] this rank needs (J = q mod Q, J > k) sit,
+            #    after step 3, in the row panels of the ranks (J mod P, q) of its own process column.  For a source
+            #    grid row pr the wanted J form an arithmetic progression (J = r mod lcm(P,Q)), so gathering them on
+            #    the source and scattering them into wcol on the receivers are single strided copies.
+            wcol = be.empty(max(nt, 1), nb)
             if nt > 0:
+                lcm = g.P * g.Q // math.gcd(g.P, g.Q)
                 for pr in range(g.P):
-                    mine = [(jl, J) for jl, J in enumerate(self.col_blocks) if J > k and J % g.P == pr]
-                    if not mine:
+                    r = next((c for c in range(lcm) if c % g.Q == g.q and c % g.P == pr), None)
+                    if r is None:
                         continue
-                    buf = be.zeros(len(mine) * nb, nb)
+                    J0 = k + 1 + ((r - (k + 1)) % lcm)                   # smallest J > k with J = r (mod lcm)
+                    if J0 >= self.nblk:
+                        continue
+                    count = (self.nblk - 1 - J0) // lcm + 1
+                    si, sj = lcm // g.P, lcm // g.Q                       # strides in local row / column blocks
+                    buf = be.empty(count * nb, nb)
                     if g.p == pr:
-                        for s, (jl, J) in enumerate(mine):
-                            il = self.row_blocks.index(J)
-                            buf[s * nb:(s + 1) * nb].copy_(wrow[(il - i0) * nb:(il - i0 + 1) * nb])
+                        il0 = (J0 - pr) // g.P - i0
+                        buf.view(count, nb, nb).copy_(wrow.view(-1, nb, nb)[il0::si][:count])
                     self._bcast_col(buf, g.q, pr)
-                    for s, (jl, J) in enumerate(mine):
-                        wcol[(jl - j0) * nb:(jl - j0 + 1) * nb].copy_(buf[s * nb:(s + 1) * nb])
-            # 5. local trailing update, one block column at a time: rows I >= J
+                    jl0 = (J0 - g.q) // g.Q - j0
+                    wcol.view(-1, nb, nb)[jl0::sj][:count].copy_(buf.view(count, nb, nb))
+            # 5. local trailing update A[I][J] -= L[I][k] L[J][k]^T for the local blocks with I >= J > k: one launch
+            #    over the local trailing matrix, tiles above the global diagonal exit at once
             if mt > 0 and nt > 0:
-                for jl in range(j0, len(self.col_blocks)):
+                be.gemm_nt_stair(A[i0 * nb:, j0 * nb:], wrow, wcol, g.P, g.p, g.Q, g.q, i0, j0, nb)
+                for jl in range(j0, len(self.col_blocks)):          # flop bookkeeping only (bench.py roofline)
                     J = self.col_blocks[jl]
-                    il = self._first_local(self.row_blocks, J - 1)          # first local row block with I >= J
-                    if il >= len(self.row_blocks):
-                        continue
-                    be.gemm_nt(A[il * nb:, jl * nb:(jl + 1) * nb], wrow[(il - i0) * nb:], wcol[(jl - j0) * nb:(jl - j0 + 1) * nb])
-                    rows = self.mloc - il * nb
-                    diag = nb if self.row_blocks[il] == J else 0          # a diagonal block counts as its lower half
-                    self.trailing_flops += 2.0 * (rows - diag) * nb * nb + diag * (nb + 1.0) * nb
+                    il = self._first_local(self.row_blocks, J - 1)
+                    if il < len(self.row_blocks):
+                        rows = self.mloc - il * nb
+                        diag = nb if self.row_blocks[il] == J else 0    # a diagonal block counts as its lower half
+                        self.trailing_flops += 2.0 * (rows - diag) * nb * nb + diag * (nb + 1.0) * nb
         # logdet and the first failing pivot, agreed by everyone
         if g.world > 1:
             s = self.be.from_numpy(np.array([logdiag]))

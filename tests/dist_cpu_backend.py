@@ -19,6 +19,11 @@ class NumpyTileBackend(object):
         shape = (rows,) if cols is None else (rows, cols)
         return self.torch.zeros(shape, dtype=self.torch.float64)
 
+    def empty(self, rows, cols=None):
+        t = self.zeros(rows, cols)
+        t.fill_(float('nan'))          # poison: an element that is read before being written shows up in the results
+        return t
+
     def from_numpy(self, a):
         return self.torch.from_numpy(np.array(a, dtype=np.float64, copy=True))
 
@@ -50,6 +55,15 @@ class NumpyTileBackend(object):
 
     def gemm_nt(self, c, a, b):
         c.numpy()[:] -= a.numpy() @ b.numpy().T
+
+    def gemm_nt_stair(self, c, a, b, P, p, Q, q, bi0, bj0, nb):
+        cn, an, bn = c.numpy(), a.numpy(), b.numpy()
+        for bj in range(cn.shape[1] // nb):
+            J = q + Q * (bj0 + bj)
+            for bi in range(cn.shape[0] // nb):
+                I = p + P * (bi0 + bi)
+                if I >= J:
+                    cn[bi * nb:(bi + 1) * nb, bj * nb:(bj + 1) * nb] -= an[bi * nb:(bi + 1) * nb] @ bn[bj * nb:(bj + 1) * nb].T
 
     def gemm_nn(self, c, a, b):
         c.numpy()[:] -= a.numpy() @ b.numpy()

@@ -84,6 +84,8 @@ def _worker(rank, world, P, Q, n, d, m, nb, port, seed):
     (2, 1, 2, 64, 16),     # N an exact multiple of nb * lcm(P, Q): no padding
     (4, 2, 2, 150, 16),    # 2 x 2 grid, ragged N
     (1, 1, 1, 37, 8),      # degenerate grid: the driver without communication
+    (6, 2, 3, 200, 8),     # coprime grid dimensions
+    (8, 2, 4, 260, 8),     # the 8-GPU grid of BASELINE.json configs[3] (gcd(P, Q) = 2: not every (row, column) residue pairs up)
 ])
 def test_block_cyclic_gloo(world, P, Q, n, nb):
     import torch.multiprocessing as mp

@@ -163,3 +163,28 @@ def test_full_size_properties(n_side, seed):
     gp_p = it.fit(x[perm], f[perm])
     assert abs(gp_p.logdet - gp.logdet) < 1e-9 * abs(gp.logdet)
     assert relmax(gp_p.alpha.to_host().reshape(-1), alpha[perm]) < 1e-8
+
+
+@pytest.mark.parametrize('P,p,Q,q,bi0,bj0,mb,nbk', [(1, 0, 1, 0, 1, 1, 5, 5), (2, 1, 4, 2, 0, 0, 6, 3), (2, 0, 4, 3, 2, 1, 4, 3),
+                                                   (2, 1, 2, 1, 3, 3, 5, 5), (3, 2, 2, 0, 1, 2, 7, 9)])
+def test_gemm_staircase_matches_block_cyclic_definition(ctx, P, p, Q, q, bi0, bj0, mb, nbk):
+    """the one-launch local trailing update of the multi-GPU driver: a 128-tile of the local matrix is updated
+    iff it lies on/below the GLOBAL diagonal of the block-cyclic matrix (exact integer data)"""
+    nb = 256
+    rng = np.random.default_rng(P * 100 + Q * 10 + p + q)
+    m, n, k = mb * nb, nbk * nb, nb
+    A = rng.integers(-4, 5, (m, k)).astype(float)
+    B = rng.integers(-4, 5, (n, k)).astype(float)
+    C = rng.integers(-50, 50, (m, n)).astype(float)
+    dA, dB, dC = dev(ctx, A), dev(ctx, B), dev(ctx, C)
+    _lib.check(ctx.lib.mgpi_gemm_nt_stair_dev(ctx.handle, dA.handle, dB.handle, dC.handle, P, p, Q, q, bi0, bj0, nb))
+    got = dC.to_host()
+    full = C - A @ B.T
+    ti = np.arange(m) // 128
+    tj = np.arange(n) // 128
+    tpb = nb // 128
+    gr = (p + P * (bi0 + ti // tpb)) * tpb + ti % tpb          # global tile row of each local row
+    gc = (q + Q * (bj0 + tj // tpb)) * tpb + tj % tpb
+    live = gr[:, None] >= gc[None, :]
+    assert np.array_equal(got[live], full[live])
+    assert np.array_equal(got[~live], C[~live])

@@ -7,7 +7,7 @@ import mgpi_amd as mgpi
 from mgpi_amd import _lib
 ctx = mgpi.default_context()
 rng = np.random.default_rng(0)
-n, m = 64, 4096
+n, m = 64, int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 K = np.eye(n) * 4 + 0.1 * rng.random((n, n)); K = K @ K.T
 L = _lib.DeviceMatrix.from_host(ctx, K, wide=True)
 _lib.check(ctx.lib.mgpi_potrf_dev(ctx.handle, L.handle, None))
