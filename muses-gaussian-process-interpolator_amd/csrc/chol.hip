@@ -95,123 +95,125 @@ int mgpi_launch_potf2(mgpi_ctx* ctx, double* A, int64_t lda, int64_t pivot_base,
 }
 
 // ---- 64-wide triangular block solves ---------------------------------------------------------------------
-// Both use the right-looking (column-sweep) form: once x_k is final, every later unknown subtracts its
-// coefficient times x_k.  The 63-k updates of a step are independent FMAs (no dependent chain), the
-// coefficients are LDS broadcasts read two at a time, and the division is a multiply by a reciprocal computed
-// once per block (LAPACK's dtrsm does the same).  The unknowns of one row/column live in 64 registers.
+// Right-looking (column-sweep) substitution: once x_k is final every later unknown subtracts its coefficient
+// times x_k, so the updates of a step are independent FMAs; the division is a multiply by a reciprocal kept on
+// the diagonal of the LDS coefficient image (LAPACK's dtrsm does the same).
+//
+// Parallel shape: FOUR lanes (one DPP quad) share one row/column of unknowns, lane part q owning unknowns
+// [16q, 16q+16).  The pivot x_k is broadcast inside the quad with one quad_perm DPP move per 32 bits.
+// Variants measured with rocprofv3 at N=32768 (us per launch, multi-rhs solve / panel trsm):
+//   v1 one thread per row, coefficients from LDS in batches of 32 ............ 37 / 22  (one wave per SIMD, 69 % of
+//      the wave time in s_waitcnt on LDS latency, SQ_WAIT_ANY)
+//   v2 (this) four lanes per row, 16 waves per CU ............................. 19 / 20  (LDS-instruction bound: every
+//      quad re-reads the coefficient triangle)
+//   v3 one thread per row, coefficients by SCALAR loads from the factor in L2 . 39 / 44  (s_load latency exposed 178x)
+// fp64 facts behind this (tools/clock_probe.hip): a dependent v_fma_f64 has 32 cycles of latency (4 to issue); a
+// division is a ~15-instruction dependent chain, hence the reciprocals.
+//
+// LDS image C[k][m]: coefficient of x_k in equation m; zero where equation m does not involve x_k (so the FMAs
+// need no predicate), 1/c_kk at m == k.
 
-// The coefficients of a step are pulled from LDS in batches of up to 32 (16 ds_read_b128 issued back to back,
-// one exposed LDS latency per batch): left to itself hipcc issued one ds_read + s_waitcnt per FMA and exposed
-// the LDS latency 2000 times.  The diagonal slot C[k][k] holds the reciprocal 1/c_kk.
-
-// forward sweep: solves sum_{m<=k} c[k][m] x_m = b_k.  Ct[k][m] (m > k) = coefficient of x_k in equation m.
-__device__ __forceinline__ void sweep_fwd(double (&x)[IB], const double (*Ct)[IB]) {
-#pragma unroll
-    for (int k = 0; k < IB; ++k) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int lo = (h == 0) ? (k & ~1) : 32, hi = (h == 0) ? 32 : IB;
-            if (k < hi && lo < hi) {
-                double c[32];
-#pragma unroll
-                for (int m = lo; m < hi; ++m) c[m - lo] = Ct[k][m];
-                __builtin_amdgcn_sched_barrier(0);
-                if (k >= lo && k < hi) x[k] *= c[k - lo];
-#pragma unroll
-                for (int m = (k + 1 > lo ? k + 1 : lo); m < hi; ++m) x[m] = fma(-c[m - lo], x[k], x[m]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-}
-// backward sweep: solves sum_{m>=k} c[m][k] x_m = b_k.  Cr[k][m] (m < k) = coefficient of x_k in equation m.
-__device__ __forceinline__ void sweep_bwd(double (&x)[IB], const double (*Cr)[IB]) {
-#pragma unroll
-    for (int k = IB - 1; k >= 0; --k) {
-#pragma unroll
-        for (int h = 1; h >= 0; --h) {
-            const int lo = (h == 0) ? 0 : 32;
-            const int end = (k + 2) & ~1;                                  // one past the diagonal, rounded to a 16-byte pair
-            const int hi0 = (h == 0) ? (end < 32 ? end : 32) : end;
-            if (k >= lo && lo < hi0) {
-                double c[32];
-#pragma unroll
-                for (int m = lo; m < hi0; ++m) c[m - lo] = Cr[k][m];
-                __builtin_amdgcn_sched_barrier(0);
-                if (k >= lo && k < hi0) x[k] *= c[k - lo];
-#pragma unroll
-                for (int m = lo; m < (k < hi0 ? k : hi0); ++m) x[m] = fma(-c[m - lo], x[k], x[m]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
+template <int SRC>
+__device__ __forceinline__ double quad_bcast(double v) {
+    constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);   // quad_perm: every lane reads quad lane SRC
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
 }
 
-// panel trsm: X L_jj^T = A for 64-row blocks, 64 columns.  One workgroup = one wave = 64 rows; thread = row.
-// x_k = (a_k - sum_{m<k} x_m L[k][m]) / L[k][k]: a forward sweep with Ct[k][m] = L[m][k], i.e. L transposed.
-// Each thread streams its own row (512 contiguous bytes) straight from HBM/L2: no staging tile, 33 KB of LDS.
-__global__ __launch_bounds__(64) void trsm_rows_kernel(const double* __restrict__ Ljj, int64_t ldl,
-                                                       double* __restrict__ A, int64_t lda) {
-    __shared__ __attribute__((aligned(16))) double Lt[IB][IB];
-    const int lane = threadIdx.x;
+template <int K>
+__device__ __forceinline__ void quad_step(double (&x)[16], const double (*C)[IB], int q) {
+    constexpr int QK = K / 16, KL = K % 16;
+    double c[16];
 #pragma unroll
-    for (int r = 0; r < IB; ++r) {   // Lt[k][m] = L[m][k]; 64 loads in flight; reciprocal on the diagonal
-        const double v = Ljj[r * ldl + lane];
-        Lt[lane][r] = (r == lane) ? 1.0 / v : v;
+    for (int j = 0; j < 16; j += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(&C[K][16 * q + j]);
+        c[j] = v.x;
+        c[j + 1] = v.y;
     }
-    double* row = A + ((int64_t)blockIdx.x * IB + lane) * lda;
-    double x[IB];
+    const double xk = quad_bcast<QK>(x[KL] * C[K][K]);       // only the owning part's product is meaningful
 #pragma unroll
-    for (int k = 0; k < IB; k += 2) {
-        const double2 v = *reinterpret_cast<const double2*>(row + k);
-        x[k] = v.x;
-        x[k + 1] = v.y;
+    for (int j = 0; j < 16; ++j) x[j] = fma(-c[j], xk, x[j]);
+    x[KL] = (q == QK) ? xk : x[KL];                             // the owner keeps the solved value
+}
+
+template <int K, bool FWD>
+struct quad_sweep {
+    static __device__ __forceinline__ void run(double (&x)[16], const double (*C)[IB], int q) {
+        quad_step<FWD ? IB - 1 - K : K>(x, C, q);               // FWD: steps 0, 1, .., 63; else 63, 62, .., 0
+        if constexpr (K > 0) quad_sweep<K - 1, FWD>::run(x, C, q);
+    }
+};
+
+// stage the 64x64 diagonal block as the coefficient image.  TRANSPOSE: C[k][m] = L[m][k] (else C[k][m] = L[k][m]);
+// KEEP_M_GT_K selects the triangle that is kept (m > k for the forward sweep, m < k for the backward one)
+template <bool TRANSPOSE, bool KEEP_M_GT_K>
+__device__ __forceinline__ void stage_coeff(const double* __restrict__ Ljj, int64_t ldl, double (*C)[IB], int tid) {
+#pragma unroll
+    for (int u = 0; u < IB * IB / 256; ++u) {
+        const int idx = tid + 256 * u, r = idx >> 6, cidx = idx & 63;   // L[r][cidx], coalesced
+        const double v = Ljj[r * ldl + cidx];
+        const int k = TRANSPOSE ? cidx : r, m = TRANSPOSE ? r : cidx;
+        const bool keep = KEEP_M_GT_K ? (m > k) : (m < k);
+        C[k][m] = (m == k) ? 1.0 / v : (keep ? v : 0.0);
+    }
+}
+
+// panel trsm: X L_jj^T = A, 64 columns; one 256-thread workgroup = 64 rows, 4 lanes per row.
+// x_k = (a_k - sum_{m<k} x_m L[k][m]) / L[k][k]: forward sweep with C[k][m] = L[m][k] (m > k).
+__global__ __launch_bounds__(256) void trsm_rows_kernel(const double* __restrict__ Ljj, int64_t ldl,
+                                                        double* __restrict__ A, int64_t lda) {
+    __shared__ __attribute__((aligned(16))) double C[IB][IB];
+    const int tid = threadIdx.x, q = tid & 3;
+    stage_coeff<true, true>(Ljj, ldl, C, tid);
+    double* row = A + ((int64_t)blockIdx.x * IB + (tid >> 2)) * lda + 16 * q;
+    double x[16];
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(row + j);
+        x[j] = v.x;
+        x[j + 1] = v.y;
     }
     __syncthreads();
-    sweep_fwd(x, Lt);
+    quad_sweep<IB - 1, true>::run(x, C, q);
 #pragma unroll
-    for (int k = 0; k < IB; k += 2) *reinterpret_cast<double2*>(row + k) = make_double2(x[k], x[k + 1]);
+    for (int j = 0; j < 16; j += 2) *reinterpret_cast<double2*>(row + j) = make_double2(x[j], x[j + 1]);
 }
 
 int mgpi_launch_trsm_rows(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double* A, int64_t lda, int64_t rows) {
     if (rows == 0) return 0;
     MGPI_REQUIRE(rows % IB == 0, "trsm_rows: rows=%lld not a multiple of %d", (long long)rows, IB);
-    hipLaunchKernelGGL(trsm_rows_kernel, dim3((unsigned)(rows / IB)), dim3(64), 0, ctx->stream, Ljj, ldl, A, lda);
+    hipLaunchKernelGGL(trsm_rows_kernel, dim3((unsigned)(rows / IB)), dim3(256), 0, ctx->stream, Ljj, ldl, A, lda);
     MGPI_HIP_TRY(hipGetLastError());
     return 0;
 }
 
 // multi-rhs 64-row block solve:  B <- L_jj^-1 B  (TRANS = false)  or  L_jj^-T B  (TRANS = true).
-// B is (64 x n) row-major; one thread per column of B (coalesced across threads), L_jj in LDS.
-//   L x = b   : forward sweep,  Ct[k][m] = L[m][k]  (L transposed)
-//   L^T x = b : backward sweep, Cr[k][m] = L[k][m]  (L as stored)
+// B is (64 x n) row-major; one 256-thread workgroup = 64 columns of B, 4 lanes per column (part q owns rows
+// [16q, 16q+16) of the block).
+//   L x = b   : forward sweep,  C[k][m] = L[m][k], m > k
+//   L^T x = b : backward sweep, C[k][m] = L[k][m], m < k
 template <bool TRANS>
-__global__ __launch_bounds__(64) void trsm_cols_kernel(const double* __restrict__ Ljj, int64_t ldl,
-                                                       double* __restrict__ B, int64_t ldb) {
-    __shared__ __attribute__((aligned(16))) double Ls[IB][IB];
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void trsm_cols_kernel(const double* __restrict__ Ljj, int64_t ldl,
+                                                        double* __restrict__ B, int64_t ldb) {
+    __shared__ __attribute__((aligned(16))) double C[IB][IB];
+    const int tid = threadIdx.x, q = tid & 3;
+    if (TRANS) stage_coeff<false, false>(Ljj, ldl, C, tid);
+    else stage_coeff<true, true>(Ljj, ldl, C, tid);
+    double* col = B + (int64_t)blockIdx.x * 64 + (tid >> 2) + (int64_t)(16 * q) * ldb;   // n is a multiple of 64
+    double x[16];
 #pragma unroll
-    for (int r = 0; r < IB; ++r) {
-        double v = Ljj[r * ldl + lane];   // L[r][lane]; reciprocal on the diagonal
-        if (r == lane) v = 1.0 / v;
-        if (TRANS) Ls[r][lane] = v;
-        else Ls[lane][r] = v;
-    }
-    double* col = B + (int64_t)blockIdx.x * 64 + lane;   // n is a multiple of 64 (tile-padded B)
-    double x[IB];
-#pragma unroll
-    for (int k = 0; k < IB; ++k) x[k] = col[k * ldb];
+    for (int j = 0; j < 16; ++j) x[j] = col[j * ldb];
     __syncthreads();
-    if (TRANS) sweep_bwd(x, Ls);
-    else sweep_fwd(x, Ls);
+    quad_sweep<IB - 1, !TRANS>::run(x, C, q);
 #pragma unroll
-    for (int k = 0; k < IB; ++k) col[k * ldb] = x[k];
+    for (int j = 0; j < 16; ++j) col[j * ldb] = x[j];
 }
 
 int mgpi_launch_trsm_cols(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double* B, int64_t ldb, int64_t n, int trans) {
     if (n == 0) return 0;
     MGPI_REQUIRE(n % 64 == 0, "trsm_cols: n=%lld is not a multiple of 64", (long long)n);
-    dim3 grid((unsigned)(n / 64)), block(64);
+    dim3 grid((unsigned)(n / 64)), block(256);
     if (trans) hipLaunchKernelGGL(trsm_cols_kernel<true>, grid, block, 0, ctx->stream, Ljj, ldl, B, ldb);
     else hipLaunchKernelGGL(trsm_cols_kernel<false>, grid, block, 0, ctx->stream, Ljj, ldl, B, ldb);
     MGPI_HIP_TRY(hipGetLastError());
