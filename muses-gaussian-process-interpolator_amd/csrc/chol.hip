@@ -280,29 +280,63 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
     MGPI_HIP_TRY(hipGetLastError());
     mgpi_prof_begin(ctx, 2);
 
-    for (int64_t r0 = 0; r0 < pn; r0 += nb) {
-        const int64_t w = (pn - r0 < nb) ? (pn - r0) : nb;   // panel width
-        // ---- panel: columns [r0, r0+w), rows [r0, pn); left-looking over 64-wide inner blocks
-        mgpi_prof_begin(ctx, 1);
+    // panel factorisation of columns [r0, r0+w), rows [r0, pn): left-looking over 64-wide inner blocks; enqueued on
+    // whatever ctx->stream currently is
+    auto factor_panel = [&](int64_t r0, int64_t w) -> int {
         for (int64_t c0 = r0; c0 < r0 + w; c0 += IB) {
             const int64_t kk = c0 - r0;
-            if (kk > 0) {
-                // A[c0:pn, c0:c0+64] -= A[c0:pn, r0:c0] * A[c0:c0+64, r0:c0]^T
+            if (kk > 0)   // A[c0:pn, c0:c0+64] -= A[c0:pn, r0:c0] * A[c0:c0+64, r0:c0]^T
                 MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, pn - c0, IB, kk, A + c0 * lda + r0, lda, A + c0 * lda + r0, lda,
                                           A + c0 * lda + c0, lda));
-            }
             MGPI_TRY(mgpi_launch_potf2(ctx, A + c0 * lda + c0, lda, c0, ctx->d_diag + c0));
             MGPI_TRY(mgpi_launch_trsm_rows(ctx, A + c0 * lda + c0, lda, A + (c0 + IB) * lda + c0, lda, pn - c0 - IB));
         }
-        mgpi_prof_end(ctx, 1);
-        // ---- trailing update (lower tiles only): A22 -= P P^T, P = A[r0+w:pn, r0:r0+w]
-        const int64_t t = pn - r0 - w;
-        if (t > 0) {
+        return 0;
+    };
+
+    // Look-ahead (depth 1): after panel k, first update ONLY the block column of panel k+1, then factor panel k+1
+    // on the second (high-priority) stream while the rest of the trailing update of panel k runs on the main
+    // stream.  The two touch disjoint columns; the next step's updates wait for the panel through an event.
+    hipStream_t main_stream = ctx->stream;
+    const bool lookahead = ctx->stream2 != nullptr && !ctx->no_lookahead;
+    mgpi_prof_begin(ctx, 1);
+    MGPI_TRY(factor_panel(0, (pn < nb) ? pn : nb));
+    mgpi_prof_end(ctx, 1);
+    for (int64_t r0 = 0; r0 < pn; r0 += nb) {
+        const int64_t w = (pn - r0 < nb) ? (pn - r0) : nb;   // panel k (already factored)
+        const int64_t t = pn - r0 - w;                        // trailing size
+        if (t <= 0) break;
+        const int64_t r1 = r0 + w;
+        const int64_t w1 = (pn - r1 < nb) ? (pn - r1) : nb;   // panel k+1
+        const double* P = A + r1 * lda + r0;                  // rows r1.., the w columns of panel k
+        // (1) block column of the next panel: A[r1:pn, r1:r1+w1] -= P P[0:w1]^T
+        mgpi_prof_begin(ctx, 0);
+        MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, t, w1, w, P, lda, P, lda, A + r1 * lda + r1, lda));
+        mgpi_prof_end(ctx, 0);
+        // (2) factor panel k+1
+        if (lookahead) {
+            MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
+            MGPI_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_upd, 0));
+            ctx->stream = ctx->stream2;
+            const int rc = factor_panel(r1, w1);
+            ctx->stream = main_stream;
+            MGPI_TRY(rc);
+            MGPI_HIP_TRY(hipEventRecord(ctx->ev_panel, ctx->stream2));
+        } else {
+            mgpi_prof_begin(ctx, 1);
+            MGPI_TRY(factor_panel(r1, w1));
+            mgpi_prof_end(ctx, 1);
+        }
+        // (3) the rest of the trailing update (lower tiles): A[r2:pn, r2:pn] -= P[w1:] P[w1:]^T
+        const int64_t t2 = t - w1;
+        if (t2 > 0) {
             mgpi_prof_begin(ctx, 0);
-            const double* P = A + (r0 + w) * lda + r0;
-            MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 1, t, t, w, P, lda, P, lda, A + (r0 + w) * lda + (r0 + w), lda));
+            const double* P2 = P + w1 * lda;
+            MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 1, t2, t2, w, P2, lda, P2, lda, A + (r1 + w1) * lda + (r1 + w1), lda));
             mgpi_prof_end(ctx, 0);
         }
+        // (4) the next step needs panel k+1
+        if (lookahead) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
     }
 
     mgpi_prof_end(ctx, 2);

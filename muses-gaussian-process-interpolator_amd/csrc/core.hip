@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <math.h>
 #include <new>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -50,6 +51,14 @@ extern "C" int mgpi_ctx_create(int device_id, int nb, mgpi_ctx** out) {
     c->device = device_id;
     c->nb = nb;
     MGPI_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        int lo = 0, hi = 0;   // numerically lowest value = highest priority
+        MGPI_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        MGPI_HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi));
+    }
+    MGPI_HIP_TRY(hipEventCreateWithFlags(&c->ev_upd, hipEventDisableTiming));
+    MGPI_HIP_TRY(hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming));
+    c->no_lookahead = getenv("MGPI_NO_LOOKAHEAD") && atoi(getenv("MGPI_NO_LOOKAHEAD")) != 0;
     MGPI_HIP_TRY(hipEventCreate(&c->ev0));
     MGPI_HIP_TRY(hipEventCreate(&c->ev1));
     MGPI_HIP_TRY(hipMalloc((void**)&c->d_info, 64));
@@ -74,6 +83,10 @@ extern "C" int mgpi_ctx_destroy(mgpi_ctx* ctx) {
         for (hipEvent_t e : ctx->prof[s].end) (void)hipEventDestroy(e);
     }
     delete[] ctx->prof;
+    (void)hipStreamSynchronize(ctx->stream2);
+    (void)hipStreamDestroy(ctx->stream2);
+    (void)hipEventDestroy(ctx->ev_upd);
+    (void)hipEventDestroy(ctx->ev_panel);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;

@@ -21,7 +21,10 @@ struct mgpi_prof_slot {
 struct mgpi_ctx {
     int device;
     int nb;                       // outer Cholesky block
-    hipStream_t stream;
+    hipStream_t stream;           // where launchers enqueue (the main stream, except during a look-ahead panel)
+    hipStream_t stream2;          // high-priority stream of the look-ahead panel factorisation
+    hipEvent_t ev_upd, ev_panel;  // next-panel column updated / next panel factored
+    int no_lookahead;             // MGPI_NO_LOOKAHEAD=1 (developer switch)
     hipEvent_t ev0, ev1;          // tic/toc
     int profile;
     mgpi_prof_slot* prof;         // [3]: 0 trailing update, 1 panel, 2 whole potrf
