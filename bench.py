@@ -75,6 +75,18 @@ def trailing_flops(n, nb=NB):
     return float(sum((pn - k * nb) * (pn - k * nb + 1) * nb for k in range(1, (pn + nb - 1) // nb)))
 
 
+def syrk_launch_flops(n, nb=NB):
+    """algorithmic flops of the lower-syrk LAUNCHES of the look-ahead factorisation: at step k the block column
+    of panel k+1 is updated by its own gemm first, the syrk covers the remaining t2 = n_k - nb rows/columns:
+    sum_k t2 (t2 + 1) nb.  (The column updates carry the rest of trailing_flops.)"""
+    pn = (n + 127) // 128 * 128
+    total = 0.0
+    for k in range(1, (pn + nb - 1) // nb):
+        t2 = pn - k * nb - min(nb, pn - k * nb)
+        total += t2 * (t2 + 1.0) * nb
+    return total
+
+
 class GpuStep(object):
     """device-resident inputs + one hot-path pass through the C-ABI"""
 
@@ -230,13 +242,14 @@ def main():
     syrk_ms, syrk_launches = ctx.get_profile(0)
     panel_ms, _ = ctx.get_profile(1)
     potrf_ms, _ = ctx.get_profile(2)
+    colupd_ms, colupd_launches = ctx.get_profile(3)
     ctx.set_profile(False)
 
     if rank == 0:
         flops = step_flops(n, m)                                  # one GP of size n, whatever the GPU count
         value = flops * args.steps / elapsed / 1e12
         if not distributed:
-            tr_flops = trailing_flops(n)
+            tr_flops = syrk_launch_flops(n)
         else:
             tr_flops = step.gp.trailing_flops / (args.steps + args.warmup)      # this rank's share, per step
         tflops_syrk = tr_flops * args.steps / (syrk_ms * 1e-3) / 1e12
@@ -255,7 +268,8 @@ def main():
                          'launches': int(syrk_launches), 'avg_launch_ms': syrk_ms / max(1, syrk_launches),
                          'algorithmic_flops_per_step': tr_flops},
             'stages_ms_per_step': {'potrf': potrf_ms / args.steps, 'potrf_trailing_update': syrk_ms / args.steps,
-                                   'potrf_panels': panel_ms / args.steps},
+                                   'potrf_next_panel_column_update': colupd_ms / args.steps,
+                                   'potrf_panels_not_overlapped': panel_ms / args.steps},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

@@ -175,7 +175,8 @@ int  mgpi_probe_hbm(mgpi_ctx* ctx, int64_t bytes, int iters, double* read_gbs, d
 
 /* per-kernel accumulated HIP-event time of the last mgpi_potrf_dev when profiling is enabled */
 int  mgpi_ctx_set_profile(mgpi_ctx* ctx, int on);
-/* which: 0 = trailing update (syrk), 1 = panel (potf2+trsm+inner gemm), 2 = total; ms and launches */
+/* which: 0 = trailing update (lower syrk launches), 1 = panel (potf2+trsm+inner gemm; only when look-ahead is off),
+ * 2 = whole potrf, 3 = look-ahead update of the next panel's block column; ms and launches */
 int  mgpi_ctx_get_profile(mgpi_ctx* ctx, int which, double* ms, int64_t* launches);
 
 #ifdef __cplusplus

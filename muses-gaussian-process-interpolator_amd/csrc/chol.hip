@@ -27,57 +27,76 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
-// One wave; lane i owns row i of the block in 64 registers (every register index below is a compile-time
-// constant after unrolling, so nothing goes to scratch).  Column k: every lane drops its entry of column k into
-// LDS, reads the pivot back as a broadcast, forms 1/sqrt(pivot), and applies the rank-1 update
-// a_i[j] -= (a_i[k] / pivot) * a_j[k] with the column read back as 16-byte broadcasts.  One LDS round trip per
-// column is the whole synchronisation (a single wave executes its LDS operations in order).
-__global__ __launch_bounds__(64) void potf2_kernel(double* __restrict__ A, int64_t lda, int64_t pivot_base,
-                                                   const double* __restrict__ diag0, int* __restrict__ info) {
-    __shared__ double T[IB][IB + 1];
-    const int lane = threadIdx.x;
-#pragma unroll
-    for (int r = 0; r < IB; ++r) T[r][lane] = A[r * lda + lane];   // 64 independent loads in flight
-    const double dg = MGPI_PIVOT_TOL * fabs(diag0[lane]);
-    __syncthreads();
-    double a[IB];
-#pragma unroll
-    for (int j = 0; j < IB; ++j) a[j] = (j <= lane) ? T[lane][j] : 0.0;
-    int bad = 0;
-    __shared__ __attribute__((aligned(16))) double col[2][IB];
-    __shared__ double dtol[IB];
-    dtol[lane] = dg;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < IB; ++k) {
-        const double raw = a[k];
-        col[k & 1][lane] = raw;
-        __syncthreads();                                   // one wave: s_waitcnt + a trivial barrier
-        const double d = col[k & 1][k];
-        const bool ok = d > dtol[k];                       // false for NaN too
-        if (!ok && bad == 0) bad = k + 1;
-        // 1/sqrt(pivot): hardware estimate + two Newton steps (the pivot chain is the critical path of the
-        // whole factorisation; a correctly rounded sqrt + divide would triple its length)
+template <int SRC>
+__device__ __forceinline__ double potf2_quad_bcast(double v) {
+    constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);   // quad_perm: every lane reads quad lane SRC
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int K>
+struct potf2_steps {
+    static __device__ __forceinline__ void run(double (&a)[16], double (*col)[IB], const double* dtol, int r, int q, int& bad) {
+        constexpr int QK = K / 16, KL = K % 16;
+        if (q == QK) col[K & 1][r] = (r >= K) ? a[KL] : 0.0;      // rows above k contribute nothing
+        __syncthreads();
+        const double d = col[K & 1][K];
+        const bool ok = d > dtol[K];                                // false for NaN too
+        if (!ok && bad == 0) bad = K + 1;
+        // 1/sqrt(pivot): hardware estimate + two Newton steps (a dependent fp64 op costs 32 cycles, so this
+        // chain, not the arithmetic volume, sets the time of the kernel)
         const double dd = ok ? d : 1.0;
         double y = __builtin_amdgcn_rsq(dd);
         y = fma(y * 0.5, fma(-dd * y, y, 1.0), y);
         y = fma(y * 0.5, fma(-dd * y, y, 1.0), y);
-        const double t = (lane > k) ? raw * (y * y) : 0.0; // a_i[k] / pivot
-        a[k] = (lane == k) ? dd * y : ((lane > k) ? raw * y : 0.0);
-        // pull the whole column into registers in one batch (one LDS latency), then the FMAs
-        double cj[IB];
+        double c[16];
 #pragma unroll
-        for (int j = k + 1; j < IB; ++j) cj[j] = col[k & 1][j];
-        __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < 16; j += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(&col[K & 1][16 * q + j]);
+            c[j] = v.x;
+            c[j + 1] = v.y;
+        }
+        const double raw = potf2_quad_bcast<QK>(a[KL]);             // this row's entry of column k
+        const double t = (r > K) ? raw * (y * y) : 0.0;             // a_r[k] / pivot; rows <= k are finished
 #pragma unroll
-        for (int j = k + 1; j < IB; ++j) a[j] = fma(-t, cj[j], a[j]);
+        for (int j = 0; j < 16; ++j) a[j] = fma(-t, c[j], a[j]);
+        // the owning part stores the factor entry: sqrt(pivot) on the diagonal, a_r[k]/sqrt(pivot) below, 0 above
+        if (q == QK) a[KL] = (r == K) ? dd * y : ((r > K) ? raw * y : 0.0);
+        if constexpr (K + 1 < IB) potf2_steps<K + 1>::run(a, col, dtol, r, q, bad);
     }
+};
+
+// 256 threads: FOUR lanes (one DPP quad) share row r of the block, lane part q owning columns [16q, 16q+16) in 16
+// registers (every register index is a compile-time constant after unrolling).  Column k: the owning parts drop
+// their entry of column k into LDS (rows above k write 0), one barrier, every lane reads the pivot and the 16
+// column entries that face its own columns, forms 1/sqrt(pivot) and applies a_r[j] -= (a_r[k]/pivot) a_j[k].
+// Footprint 1.5 KB of LDS and < 104 VGPRs on purpose: with the look-ahead this kernel has to be able to start on
+// a CU that already runs two trailing-update workgroups (128 KB LDS, 2 x 200 VGPRs per SIMD) instead of waiting
+// ~300 us for one of them to finish (an earlier single-wave version held the row in 128 VGPRs and a 33 KB
+// staging tile and did wait).
+__global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int64_t lda, int64_t pivot_base,
+                                                    const double* __restrict__ diag0, int* __restrict__ info) {
+    __shared__ __attribute__((aligned(16))) double col[2][IB];
+    __shared__ double dtol[IB];
+    const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
+    double* row = A + (int64_t)r * lda + 16 * q;
+    double a[16];
 #pragma unroll
-    for (int j = 0; j < IB; ++j) T[lane][j] = (j <= lane) ? a[j] : 0.0;
-    __syncthreads();
+    for (int j = 0; j < 16; j += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(row + j);
+        a[j] = (16 * q + j <= r) ? v.x : 0.0;           // only the lower triangle is read
+        a[j + 1] = (16 * q + j + 1 <= r) ? v.y : 0.0;
+    }
+    if (q == 0) dtol[r] = MGPI_PIVOT_TOL * fabs(diag0[r]);
+    int bad = 0;
+    potf2_steps<0>::run(a, col, dtol, r, q, bad);
 #pragma unroll
-    for (int r = 0; r < IB; ++r) A[r * lda + lane] = T[r][lane];
-    if (lane == 0 && bad != 0) {
+    for (int j = 0; j < 16; j += 2) {
+        const double2 v = make_double2((16 * q + j <= r) ? a[j] : 0.0, (16 * q + j + 1 <= r) ? a[j + 1] : 0.0);
+        *reinterpret_cast<double2*>(row + j) = v;
+    }
+    if (tid == 0 && bad != 0) {
         const int cand = (int)(pivot_base + bad);
         int old = atomicCAS(info, 0, cand);
         while (old != 0 && old > cand) {
@@ -89,7 +108,7 @@ __global__ __launch_bounds__(64) void potf2_kernel(double* __restrict__ A, int64
 }
 
 int mgpi_launch_potf2(mgpi_ctx* ctx, double* A, int64_t lda, int64_t pivot_base, const double* diag0) {
-    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(64), 0, ctx->stream, A, lda, pivot_base, diag0, ctx->d_info);
+    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, pivot_base, diag0, ctx->d_info);
     MGPI_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -310,15 +329,17 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
         const int64_t w1 = (pn - r1 < nb) ? (pn - r1) : nb;   // panel k+1
         const double* P = A + r1 * lda + r0;                  // rows r1.., the w columns of panel k
         // (1) block column of the next panel: A[r1:pn, r1:r1+w1] -= P P[0:w1]^T
-        mgpi_prof_begin(ctx, 0);
+        mgpi_prof_begin(ctx, 3);
         MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, t, w1, w, P, lda, P, lda, A + r1 * lda + r1, lda));
-        mgpi_prof_end(ctx, 0);
+        mgpi_prof_end(ctx, 3);
         // (2) factor panel k+1
         if (lookahead) {
             MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
             MGPI_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_upd, 0));
             ctx->stream = ctx->stream2;
+            ctx->lean = 1;
             const int rc = factor_panel(r1, w1);
+            ctx->lean = 0;
             ctx->stream = main_stream;
             MGPI_TRY(rc);
             MGPI_HIP_TRY(hipEventRecord(ctx->ev_panel, ctx->stream2));

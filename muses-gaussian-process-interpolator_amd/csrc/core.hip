@@ -47,7 +47,7 @@ extern "C" int mgpi_ctx_create(int device_id, int nb, mgpi_ctx** out) {
     mgpi_ctx* c = new (std::nothrow) mgpi_ctx();
     if (!c) { mgpi_set_error("mgpi_ctx_create: out of host memory"); return MGPI_ERR_ALLOC; }
     memset((void*)c, 0, sizeof(*c));
-    c->prof = new mgpi_prof_slot[3]();
+    c->prof = new mgpi_prof_slot[4]();
     c->device = device_id;
     c->nb = nb;
     MGPI_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -78,7 +78,7 @@ extern "C" int mgpi_ctx_destroy(mgpi_ctx* ctx) {
     (void)hipFree(ctx->d_scal);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < 4; ++s) {
         for (hipEvent_t e : ctx->prof[s].begin) (void)hipEventDestroy(e);
         for (hipEvent_t e : ctx->prof[s].end) (void)hipEventDestroy(e);
     }
@@ -120,7 +120,7 @@ extern "C" int mgpi_ctx_set_profile(mgpi_ctx* ctx, int on) {
     MGPI_REQUIRE(ctx != nullptr, "mgpi_ctx_set_profile: null ctx");
     MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->profile = on;
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < 4; ++s) {
         ctx->prof[s].used = 0;
         ctx->prof[s].ms = 0.0;
         ctx->prof[s].launches = 0;
@@ -130,7 +130,7 @@ extern "C" int mgpi_ctx_set_profile(mgpi_ctx* ctx, int on) {
 
 // sums the recorded event pairs (after draining the stream)
 extern "C" int mgpi_ctx_get_profile(mgpi_ctx* ctx, int which, double* ms, int64_t* launches) {
-    MGPI_REQUIRE(ctx != nullptr && which >= 0 && which < 3, "mgpi_ctx_get_profile: bad argument");
+    MGPI_REQUIRE(ctx != nullptr && which >= 0 && which < 4, "mgpi_ctx_get_profile: bad argument");
     MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
     mgpi_prof_slot& p = ctx->prof[which];
     double total = 0.0;

@@ -451,6 +451,7 @@ static bool use_glds() {
 template <bool AK, bool BKM>
 static int launch_shape(mgpi_ctx* ctx, int lower_only, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda,
                         const double* B, int64_t ldb, double* C, int64_t ldc) {
+    if (ctx->lean && !lower_only) return launch_one<64, 64, AK, BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
     if (lower_only) {
         MGPI_REQUIRE(m == n && m % 128 == 0, "gemm(lower): needs m == n, multiple of 128 (got %lld x %lld)", (long long)m,
                      (long long)n);

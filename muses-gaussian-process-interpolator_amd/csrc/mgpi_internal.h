@@ -25,9 +25,11 @@ struct mgpi_ctx {
     hipStream_t stream2;          // high-priority stream of the look-ahead panel factorisation
     hipEvent_t ev_upd, ev_panel;  // next-panel column updated / next panel factored
     int no_lookahead;             // MGPI_NO_LOOKAHEAD=1 (developer switch)
+    int lean;                     // launch gemms as 64x64 tiles (32 KB LDS, < 104 VGPRs): they can then start next to
+                                  // two resident trailing-update workgroups during the look-ahead
     hipEvent_t ev0, ev1;          // tic/toc
     int profile;
-    mgpi_prof_slot* prof;         // [3]: 0 trailing update, 1 panel, 2 whole potrf
+    mgpi_prof_slot* prof;         // [4]: 0 trailing update (lower syrk), 1 panel, 2 whole potrf, 3 next-panel column update
     int* d_info;                  // device: first failing pivot (0 = none)
     double* d_scal;               // device scratch scalars (logdet partials etc.), 4096 doubles
     double* d_diag;               // diag(K) before factoring (pivot threshold), grown on demand

@@ -27,6 +27,7 @@ import time
 import numpy as np
 
 from . import _lib
+from .hyper import HyperParameterSearch
 from .kernel_objects import Kernel
 
 __all__ = ['Interpolator', 'FittedGP']
@@ -137,7 +138,7 @@ class FittedGP(object):
         return self.cov_dev(self._targets(target_x)).to_host()
 
 
-class Interpolator(object):
+class Interpolator(HyperParameterSearch):
     """general Gaussian-process regression, no structure assumed in the covariance
     (the reference's class of the same name, interpolators.py:47)"""
 

@@ -9,6 +9,8 @@ def test_flop_formulas_match_survey_8d():
     t = bench.trailing_flops(32768)
     assert abs(t - 1.1455e13) / 1.1455e13 < 1e-3
     assert abs(t / (32768**3 / 3.0) - 0.977) < 2e-3
+    # the look-ahead split: syrk launches + next-panel column updates (t * nb * nb * 2 each, minus nothing) ~ the total
+    assert bench.syrk_launch_flops(32768) < t and bench.syrk_launch_flops(32768) > 0.93 * t
     n, m = 32768, 4096
     assert bench.step_flops(n, m) == n**3 / 3.0 + 2.0 * n * n + float(n) * n * m + 2.0 * m * n
 

@@ -250,3 +250,19 @@ def test_kernel_call_is_the_pairwise_matrix():
     assert_K_close(k(g['xs'], g['x']), g['Ks'])
     both = k + product_kernel(g, 'nugget')
     assert_K_close(both(g['x']), g['K'])
+
+
+def test_optimize_kernel_recovers_a_better_likelihood():
+    """optimize_kernel (scipy TNC over the device loglikelihood) must not lower the likelihood and must leave
+    the kernel at the parameters it returns"""
+    rng = np.random.default_rng(23)
+    x = rng.random((150, 1)) * 4
+    f = np.sin(2 * x[:, 0]) + 0.05 * rng.standard_normal(150)
+    k = mgpi.SquaredExponentialKernel(0.5, 0.2)
+    it = mgpi.Interpolator(k, nugget=mgpi.WhiteNoiseKernel(0.05))
+    before = it.loglikelihood(x, f)
+    np.random.seed(3)
+    out = it.optimize_kernel(x, f)
+    after = it.loglikelihood(x, f)
+    assert after >= before - 1e-9
+    assert out.dtype.names == ('sigma', 'length0') and out['sigma'][0] == k.params[0] and out['length0'][0] == k.params[1]

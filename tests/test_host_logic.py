@@ -147,3 +147,21 @@ def test_make_terms_limits():
         mgpi._lib.make_terms([(0, 1.0, tuple(range(1, 18)))])
     arr, n = mgpi._lib.make_terms([(0, 2.0, (1.0, 3.0)), (1, 0.5, ())])
     assert n == 2 and arr[0].sigma == 2.0 and arr[0].length[1] == 3.0 and arr[1].type == 1
+
+
+def test_logposterior_guards_without_touching_the_gpu():
+    """non-positive / NaN parameters and prior-excluded points return -inf before any device work
+    (interpolators.py:371-379); fixed parameters are applied and left out of the free set"""
+    from mgpi_amd.hyper import LogPosterior, initial_points
+    k = mgpi.SquaredExponentialKernel(1.0, 0.5, 0.7)
+    it = mgpi.Interpolator(k)
+    lp = LogPosterior(it, np.zeros((3, 2)), np.zeros(3), fixed={'length1': 0.9})
+    assert lp.free == ['sigma', 'length0'] and k.params[2] == 0.9
+    assert lp([-1.0, 1.0]) == -np.inf and lp([np.nan, 1.0]) == -np.inf
+    lp2 = LogPosterior(it, np.zeros((3, 2)), np.zeros(3), logprior=lambda p: -np.inf)
+    assert lp2([1.0, 1.0, 1.0]) == -np.inf
+    pts = initial_points(it, size=5, rng=np.random.default_rng(0))
+    assert pts.shape == (5, 3) and np.all(pts > 0)
+    pts = initial_points(it, fixed={'sigma': 1.0}, size=4, rng=np.random.default_rng(0))
+    assert pts.shape == (4, 2)
+    assert hasattr(it, 'optimize_kernel') and hasattr(it, 'sample_kernel')
