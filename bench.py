@@ -239,10 +239,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    syrk_ms, syrk_launches = ctx.get_profile(0)
-    panel_ms, _ = ctx.get_profile(1)
-    potrf_ms, _ = ctx.get_profile(2)
-    colupd_ms, colupd_launches = ctx.get_profile(3)
+    # untimed extra: the same kernel with the look-ahead off, i.e. without a panel factorisation running beside it
+    iso = None
+    if not distributed:
+        timed = [ctx.get_profile(i) for i in range(4)]
+        ctx.set_lookahead(False)
+        ctx.set_profile(True)
+        step.run()
+        ctx.sync()
+        iso_ms, iso_launches = ctx.get_profile(0)
+        ctx.set_lookahead(True)
+        iso = syrk_launch_flops(n) / (iso_ms * 1e-3) / 1e12
+        (syrk_ms, syrk_launches), (panel_ms, _), (potrf_ms, _), (colupd_ms, colupd_launches) = timed
+    else:
+        syrk_ms, syrk_launches = ctx.get_profile(0)
+        panel_ms, _ = ctx.get_profile(1)
+        potrf_ms, _ = ctx.get_profile(2)
+        colupd_ms, colupd_launches = ctx.get_profile(3)
     ctx.set_profile(False)
 
     if rank == 0:
@@ -266,7 +279,9 @@ def main():
                          'traffic': load_traffic(args.workload) if not distributed else None,
                          'kernel': 'gemm_f64_kernel<128,128,NT%s> (Cholesky trailing update%s)' % ((',lower', ', syrk') if not distributed else ('', ', rank 0 local blocks')),
                          'launches': int(syrk_launches), 'avg_launch_ms': syrk_ms / max(1, syrk_launches),
-                         'algorithmic_flops_per_step': tr_flops},
+                         'algorithmic_flops_per_step': tr_flops,
+                         'note': 'timed region runs with look-ahead: a panel factorisation shares the GPU with this kernel',
+                         'isolated_achieved': iso, 'isolated_frac': (iso / PEAK_FP64_MFMA_TFLOPS) if iso else None},
             'stages_ms_per_step': {'potrf': potrf_ms / args.steps, 'potrf_trailing_update': syrk_ms / args.steps,
                                    'potrf_next_panel_column_update': colupd_ms / args.steps,
                                    'potrf_panels_not_overlapped': panel_ms / args.steps},

@@ -173,6 +173,9 @@ int  mgpi_gemv_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* x, mgpi_mat
 int  mgpi_probe_mfma_f64(mgpi_ctx* ctx, int iters, double* tflops);
 int  mgpi_probe_hbm(mgpi_ctx* ctx, int64_t bytes, int iters, double* read_gbs, double* write_gbs);
 
+/* look-ahead on/off (default on; MGPI_NO_LOOKAHEAD=1 starts with it off).  Off = the panel and the trailing update run
+ * back to back on one stream: used by bench.py to time the trailing-update kernel without a concurrent panel */
+int  mgpi_ctx_set_lookahead(mgpi_ctx* ctx, int on);
 /* per-kernel accumulated HIP-event time of the last mgpi_potrf_dev when profiling is enabled */
 int  mgpi_ctx_set_profile(mgpi_ctx* ctx, int on);
 /* which: 0 = trailing update (lower syrk launches), 1 = panel (potf2+trsm+inner gemm; only when look-ahead is off),

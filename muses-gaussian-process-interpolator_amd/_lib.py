@@ -87,6 +87,7 @@ _SIGNATURES = {
     'mgpi_gemv_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int]),
     'mgpi_probe_mfma_f64': (ctypes.c_int, [_vp, ctypes.c_int, c_double_p]),
     'mgpi_probe_hbm': (ctypes.c_int, [_vp, c_int64, ctypes.c_int, c_double_p, c_double_p]),
+    'mgpi_ctx_set_lookahead': (ctypes.c_int, [_vp, ctypes.c_int]),
     'mgpi_ctx_set_profile': (ctypes.c_int, [_vp, ctypes.c_int]),
     'mgpi_ctx_get_profile': (ctypes.c_int, [_vp, ctypes.c_int, c_double_p, ctypes.POINTER(c_int64)]),
 }
@@ -244,6 +245,9 @@ class Context(object):
         ms = ctypes.c_double(0.0)
         check(self.lib.mgpi_ctx_toc(self.handle, ctypes.byref(ms)))
         return ms.value
+
+    def set_lookahead(self, on):
+        check(self.lib.mgpi_ctx_set_lookahead(self.handle, int(bool(on))))
 
     def set_profile(self, on):
         check(self.lib.mgpi_ctx_set_profile(self.handle, int(bool(on))))

@@ -386,8 +386,8 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
     const double* L = Lm->d;
     const int64_t nc = mgpi_roundup(ncols, 64);
     if (!trans) {
-        for (int64_t r0 = 0; r0 < pn; r0 += nb) {
-            const int64_t w = (pn - r0 < nb) ? (pn - r0) : nb;
+        // rows [r0, r0+w) of B <- L_bb^-1 (rows of B): 64-wide inner blocks, left-looking inside the outer block
+        auto solve_diag_block = [&](int64_t r0, int64_t w) -> int {
             for (int64_t c0 = r0; c0 < r0 + w; c0 += IB) {
                 const int64_t kk = c0 - r0;
                 if (kk > 0)   // B[c0:c0+64,:] -= L[c0:c0+64, r0:c0] * B[r0:c0,:]
@@ -395,10 +395,41 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
                                               B + c0 * ldb, ldb));
                 MGPI_TRY(mgpi_launch_trsm_cols(ctx, L + c0 * lda + c0, lda, B + c0 * ldb, ldb, ncols, 0));
             }
+            return 0;
+        };
+        // look-ahead as in the factorisation: the rows of the next outer block are updated first and solved on the
+        // second stream (lean kernels) while the rest of the update runs on the main stream
+        hipStream_t main_stream = ctx->stream;
+        const bool lookahead = ctx->stream2 != nullptr && !ctx->no_lookahead;
+        MGPI_TRY(solve_diag_block(0, (pn < nb) ? pn : nb));
+        for (int64_t r0 = 0; r0 < pn; r0 += nb) {
+            const int64_t w = (pn - r0 < nb) ? (pn - r0) : nb;
             const int64_t t = pn - r0 - w;
-            if (t > 0)        // B[r0+w:,:] -= L[r0+w:, r0:r0+w] * B[r0:r0+w,:]
-                MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, t, nc, w, L + (r0 + w) * lda + r0, lda, B + r0 * ldb, ldb,
-                                          B + (r0 + w) * ldb, ldb));
+            if (t <= 0) break;
+            const int64_t r1 = r0 + w;
+            const int64_t w1 = (pn - r1 < nb) ? (pn - r1) : nb;
+            // (1) B[r1:r1+w1,:] -= L[r1:r1+w1, r0:r0+w] * B[r0:r0+w,:]
+            MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, w1, nc, w, L + r1 * lda + r0, lda, B + r0 * ldb, ldb, B + r1 * ldb, ldb));
+            // (2) solve the next diagonal block
+            if (lookahead) {
+                MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
+                MGPI_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_upd, 0));
+                ctx->stream = ctx->stream2;
+                ctx->lean = 1;
+                const int rc = solve_diag_block(r1, w1);
+                ctx->lean = 0;
+                ctx->stream = main_stream;
+                MGPI_TRY(rc);
+                MGPI_HIP_TRY(hipEventRecord(ctx->ev_panel, ctx->stream2));
+            } else {
+                MGPI_TRY(solve_diag_block(r1, w1));
+            }
+            // (3) the remaining rows: B[r1+w1:,:] -= L[r1+w1:, r0:r0+w] * B[r0:r0+w,:]
+            const int64_t t2 = t - w1;
+            if (t2 > 0)
+                MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, t2, nc, w, L + (r1 + w1) * lda + r0, lda, B + r0 * ldb, ldb,
+                                          B + (r1 + w1) * ldb, ldb));
+            if (lookahead) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
         }
     } else {
         const int64_t nblk = (pn + nb - 1) / nb;

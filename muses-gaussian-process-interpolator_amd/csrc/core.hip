@@ -116,6 +116,12 @@ extern "C" int mgpi_ctx_toc(mgpi_ctx* ctx, double* ms) {
     return 0;
 }
 
+extern "C" int mgpi_ctx_set_lookahead(mgpi_ctx* ctx, int on) {
+    MGPI_REQUIRE(ctx != nullptr, "mgpi_ctx_set_lookahead: null ctx");
+    ctx->no_lookahead = on ? 0 : 1;
+    return 0;
+}
+
 extern "C" int mgpi_ctx_set_profile(mgpi_ctx* ctx, int on) {
     MGPI_REQUIRE(ctx != nullptr, "mgpi_ctx_set_profile: null ctx");
     MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
