@@ -3,8 +3,10 @@
 // (mgpi/interpolators.py:92,179,339,343): alpha = L^-T L^-1 f, logdet = 2 sum log L_ii.
 //
 // Two-level blocking: outer block nb (ctx->nb, default 512) for the trailing update on fp64 MFMA (gemm.hip),
-// inner block 64 for the panel: 64x64 potf2 in LDS, 64-wide row trsm with L_jj in LDS, MFMA gemm for the
-// panel-internal (left-looking) updates.
+// inner block 64 for the panel: 64x64 potf2 (four lanes per row, registers + a 1 KB LDS column buffer), 64-wide
+// row trsm (four lanes per row, L_jj as an LDS coefficient image), MFMA gemm for the panel-internal
+// (left-looking) updates.  Look-ahead of depth one: panel k+1 is factored on a second stream, with kernels lean
+// enough to start beside two resident trailing-update workgroups, while the trailing update of panel k runs.
 #include "mgpi_internal.h"
 #include <math.h>
 #include <vector>

@@ -224,18 +224,18 @@ extern "C" int mgpi_condition_cov_dev(mgpi_ctx* ctx, const mgpi_mat* Xs, const m
 // ---- throughput probes (bench.py roofline leg) ------------------------------------------------------------
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void probe_mfma_kernel(int iters, double* out) {
-    double4_t acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+// back-to-back fp64 MFMAs on register operands.  The accumulators are pinned to arch VGPRs ("+v"): left to hipcc
+// they land in AGPRs, where this instruction issues at 148 instead of 64 cycles (tools/mfma_probe2.hip).
+#define MGPI_MFMA_V(acc, a, b) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+__global__ __launch_bounds__(256) void probe_mfma_kernel(int iters, const double* in, double* out) {
+    double4_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+    const double a0 = in[threadIdx.x], a1 = in[256 + threadIdx.x], b0 = a1 + 1.0, b1 = a0 - 1.0, b2 = a0 * 0.5, b3 = a1 * 0.25;
     for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        MGPI_MFMA_V(c0, a0, b0); MGPI_MFMA_V(c1, a0, b1); MGPI_MFMA_V(c2, a0, b2); MGPI_MFMA_V(c3, a0, b3);
+        MGPI_MFMA_V(c4, a1, b0); MGPI_MFMA_V(c5, a1, b1); MGPI_MFMA_V(c6, a1, b2); MGPI_MFMA_V(c7, a1, b3);
     }
-    double s = 0.0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    const double4_t s4 = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+    const double s = s4[0] + s4[1] + s4[2] + s4[3];
     if (s == 12345.678) out[0] = s;   // keep the chain live
 }
 
@@ -243,9 +243,19 @@ extern "C" int mgpi_probe_mfma_f64(mgpi_ctx* ctx, int iters, double* tflops) {
     MGPI_REQUIRE(ctx && tflops && iters > 0, "mgpi_probe_mfma_f64: bad argument");
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
     const int blocks = 256 * 2;   // 2 workgroups of 4 waves per CU
-    hipLaunchKernelGGL(probe_mfma_kernel, dim3(blocks), dim3(256), 0, ctx->stream, 16, ctx->d_scal);   // warm-up
+    // operands: non-trivial values (the clock the chip holds depends on the data, cdna_hip_programming.md rule 25)
+    MGPI_TRY(mgpi_ensure_work(ctx, 512 * sizeof(double)));
+    double h[512];
+    unsigned long long lcg = 88172645463325252ull;
+    for (int i = 0; i < 512; ++i) {
+        lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+        h[i] = (double)(lcg >> 11) / 9007199254740992.0 * 2.0 - 1.0;
+    }
+    MGPI_HIP_TRY(hipMemcpyAsync(ctx->work, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+    MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    hipLaunchKernelGGL(probe_mfma_kernel, dim3(blocks), dim3(256), 0, ctx->stream, 16, ctx->work, ctx->d_scal);   // warm-up
     MGPI_TRY(mgpi_ctx_tic(ctx));
-    hipLaunchKernelGGL(probe_mfma_kernel, dim3(blocks), dim3(256), 0, ctx->stream, iters, ctx->d_scal);
+    hipLaunchKernelGGL(probe_mfma_kernel, dim3(blocks), dim3(256), 0, ctx->stream, iters, ctx->work, ctx->d_scal);
     double ms = 0.0;
     MGPI_TRY(mgpi_ctx_toc(ctx, &ms));
     const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2048.0;   // 16*16*4*2 per MFMA
