@@ -83,7 +83,7 @@ class ProcessGrid(object):
 class HipTileBackend(object):
     """tile operations on torch CUDA tensors through libmgpi_hip.so (the same kernels as the 1-GPU path)"""
 
-    def __init__(self, torch, ctx=None):
+    def __init__(self, torch, ctx=None, make_current=True):
         self.torch = torch
         self.ctx = ctx if ctx is not None else _lib.default_context()
         self.lib = self.ctx.lib
@@ -93,7 +93,36 @@ class HipTileBackend(object):
         # the current stream, so no host-side synchronisation is needed for correctness
         torch.cuda.set_device(self.device)
         self.stream = torch.cuda.ExternalStream(self.lib.mgpi_ctx_stream(self.ctx.handle), device=self.device)
-        torch.cuda.set_stream(self.stream)
+        if make_current:
+            torch.cuda.set_stream(self.stream)
+        self._side = None
+        self._side_done = None
+
+    # -- second stream for the look-ahead panel (its own mgpi ctx = its own HIP stream and workspace) -----------
+    def side_backend(self):
+        if self._side is None:
+            ctx2 = _lib.Context(device=self.ctx.device, nb=0)
+            self._side = HipTileBackend(self.torch, ctx2, make_current=False)
+        return self._side
+
+    def record(self):
+        """event on the main stream"""
+        ev = self.torch.cuda.Event()
+        ev.record(self.stream)
+        return ev
+
+    def on_side(self, after):
+        """context: torch's current stream = the side stream, which first waits for the event `after`"""
+        side = self.side_backend()
+        side.stream.wait_event(after)
+        return self.torch.cuda.stream(side.stream)
+
+    def join_side(self):
+        """the main stream waits for everything queued on the side stream so far"""
+        side = self.side_backend()
+        ev = self.torch.cuda.Event()
+        ev.record(side.stream)
+        self.stream.wait_event(ev)
 
     # -- memory -------------------------------------------------------------------------------------------
     def zeros(self, rows, cols=None):
@@ -309,72 +338,127 @@ class DistributedGP(object):
         be.fence()
 
     # -- factor -------------------------------------------------------------------------------------------
-    def factor(self):
-        g, be, nb = self.g, self.be, self.nb
-        A = self.A
-        info_first = 0
-        logdiag = 0.0
-        for k in range(self.nblk):
-            pk, qk = k % g.P, k % g.Q
-            kr, kc = k // g.P, k // g.Q                      # local block indices on the owners
-            i0 = self._first_local(self.row_blocks, k)       # local row blocks [i0:) have I > k
-            j0 = self._first_local(self.col_blocks, k)
-            mt = self.mloc - i0 * nb                         # local trailing rows
-            nt = self.nloc - j0 * nb
-            # 1. diagonal block
-            lkk = be.empty(nb, nb)
-            if g.q == qk:
-                if g.p == pk:
-                    blk = A[kr * nb:(kr + 1) * nb, kc * nb:(kc + 1) * nb]
-                    info, ld = be.potrf(blk)
-                    if info > 0 and info_first == 0:
-                        info_first = k * nb + info
-                    logdiag += ld
-                    lkk.copy_(blk)
-                self._bcast_col(lkk, qk, pk)
-                # 2. panel trsm on this process column
-                if mt > 0:
-                    be.trsm_right(lkk, A[i0 * nb:, kc * nb:(kc + 1) * nb])
-            # 3. panel along process rows
-            wrow = be.empty(max(mt, 1), nb)
+    def _panel(self, k, be, bufs):
+        """block step k, everything that is not the trailing update: factor the diagonal block, solve the panel
+        below it, and move the panel to every rank that needs it (row panel `wrow` for the local block rows I > k,
+        column panel `wcol` for the local block columns J > k).  Runs on whatever stream `be` enqueues to."""
+        g, nb, A = self.g, self.nb, self.A
+        pk, qk = k % g.P, k % g.Q
+        kr, kc = k // g.P, k // g.Q                      # local block indices on the owners
+        i0 = self._first_local(self.row_blocks, k)       # local row blocks [i0:) have I > k
+        j0 = self._first_local(self.col_blocks, k)
+        mt = self.mloc - i0 * nb                         # local trailing rows
+        nt = self.nloc - j0 * nb
+        info, ld = 0, 0.0
+        lkk = bufs['lkk']
+        wrow = bufs['wrow'][:max(mt, 1)]
+        wcol = bufs['wcol'][:max(nt, 1)]
+        # 1. diagonal block, down its process column
+        if g.q == qk:
+            if g.p == pk:
+                blk = A[kr * nb:(kr + 1) * nb, kc * nb:(kc + 1) * nb]
+                info, ld = be.potrf(blk)
+                if info > 0:
+                    info = k * nb + info
+                lkk.copy_(blk)
+            self._bcast_col(lkk, qk, pk)
+            # 2. panel trsm on this process column
             if mt > 0:
-                if g.q == qk:
-                    wrow.copy_(A[i0 * nb:, kc * nb:(kc + 1) * nb])
-                self._bcast_row(wrow, g.p, qk)
-            # 4. transposed role along process columns.  The blocks L[J][k] this rank needs (J = q mod Q, J > k) sit,
-            #    after step 3, in the row panels of the ranks (J mod P, q) of its own process column.  For a source
-            #    grid row pr the wanted J form an arithmetic progression (J = r mod lcm(P,Q)), so gathering them on
-            #    the source and scattering them into wcol on the receivers are single strided copies.
-            wcol = be.empty(max(nt, 1), nb)
-            if nt > 0:
-                lcm = g.P * g.Q // math.gcd(g.P, g.Q)
-                for pr in range(g.P):
-                    r = next((c for c in range(lcm) if c % g.Q == g.q and c % g.P == pr), None)
-                    if r is None:
-                        continue
-                    J0 = k + 1 + ((r - (k + 1)) % lcm)                   # smallest J > k with J = r (mod lcm)
-                    if J0 >= self.nblk:
-                        continue
-                    count = (self.nblk - 1 - J0) // lcm + 1
-                    si, sj = lcm // g.P, lcm // g.Q                       # strides in local row / column blocks
-                    buf = be.empty(count * nb, nb)
-                    if g.p == pr:
-                        il0 = (J0 - pr) // g.P - i0
-                        buf.view(count, nb, nb).copy_(wrow.view(-1, nb, nb)[il0::si][:count])
-                    self._bcast_col(buf, g.q, pr)
-                    jl0 = (J0 - g.q) // g.Q - j0
-                    wcol.view(-1, nb, nb)[jl0::sj][:count].copy_(buf.view(count, nb, nb))
-            # 5. local trailing update A[I][J] -= L[I][k] L[J][k]^T for the local blocks with I >= J > k: one launch
-            #    over the local trailing matrix, tiles above the global diagonal exit at once
-            if mt > 0 and nt > 0:
-                be.gemm_nt_stair(A[i0 * nb:, j0 * nb:], wrow, wcol, g.P, g.p, g.Q, g.q, i0, j0, nb)
-                for jl in range(j0, len(self.col_blocks)):          # flop bookkeeping only (bench.py roofline)
-                    J = self.col_blocks[jl]
-                    il = self._first_local(self.row_blocks, J - 1)
-                    if il < len(self.row_blocks):
-                        rows = self.mloc - il * nb
-                        diag = nb if self.row_blocks[il] == J else 0    # a diagonal block counts as its lower half
-                        self.trailing_flops += 2.0 * (rows - diag) * nb * nb + diag * (nb + 1.0) * nb
+                be.trsm_right(lkk, A[i0 * nb:, kc * nb:(kc + 1) * nb])
+        # 3. panel along process rows
+        if mt > 0:
+            if g.q == qk:
+                wrow.copy_(A[i0 * nb:, kc * nb:(kc + 1) * nb])
+            self._bcast_row(wrow, g.p, qk)
+        # 4. transposed role along process columns.  The blocks L[J][k] this rank needs (J = q mod Q, J > k) sit,
+        #    after step 3, in the row panels of the ranks (J mod P, q) of its own process column.  For a source
+        #    grid row pr the wanted J form an arithmetic progression (J = r mod lcm(P,Q)), so gathering them on
+        #    the source and scattering them into wcol on the receivers are single strided copies.
+        if nt > 0:
+            lcm = g.P * g.Q // math.gcd(g.P, g.Q)
+            for pr in range(g.P):
+                r = next((c for c in range(lcm) if c % g.Q == g.q and c % g.P == pr), None)
+                if r is None:
+                    continue
+                J0 = k + 1 + ((r - (k + 1)) % lcm)                   # smallest J > k with J = r (mod lcm)
+                if J0 >= self.nblk:
+                    continue
+                count = (self.nblk - 1 - J0) // lcm + 1
+                si, sj = lcm // g.P, lcm // g.Q                       # strides in local row / column blocks
+                buf = bufs['gather'][:count * nb]
+                if g.p == pr:
+                    il0 = (J0 - pr) // g.P - i0
+                    buf.view(count, nb, nb).copy_(wrow.view(-1, nb, nb)[il0::si][:count])
+                self._bcast_col(buf, g.q, pr)
+                jl0 = (J0 - g.q) // g.Q - j0
+                wcol.view(-1, nb, nb)[jl0::sj][:count].copy_(buf.view(count, nb, nb))
+        return dict(wrow=wrow, wcol=wcol, i0=i0, j0=j0, mt=mt, nt=nt, info=info, logdiag=ld)
+
+    def _update(self, pan, c_lo, c_hi, be):
+        """trailing update of the local block columns [c_lo, c_hi) with the panel of one block step:
+        A[I][J] -= L[I][k] L[J][k]^T for the local blocks with I >= J.  One launch (staircase gemm)."""
+        g, nb = self.g, self.nb
+        i0, j0 = pan['i0'], pan['j0']
+        c_hi = min(c_hi, len(self.col_blocks))
+        if pan['mt'] <= 0 or c_lo >= c_hi:
+            return
+        be.gemm_nt_stair(self.A[i0 * nb:, c_lo * nb:c_hi * nb], pan['wrow'], pan['wcol'][(c_lo - j0) * nb:(c_hi - j0) * nb],
+                         g.P, g.p, g.Q, g.q, i0, c_lo, nb)
+        for jl in range(c_lo, c_hi):                             # flop bookkeeping only (bench.py roofline)
+            J = self.col_blocks[jl]
+            il = self._first_local(self.row_blocks, J - 1)
+            if il < len(self.row_blocks):
+                rows = self.mloc - il * nb
+                diag = nb if self.row_blocks[il] == J else 0      # a diagonal block counts as its lower half
+                self.trailing_flops += 2.0 * (rows - diag) * nb * nb + diag * (nb + 1.0) * nb
+
+    def factor(self, lookahead=None):
+        """2-D block-cyclic right-looking Cholesky.  With look-ahead (default; MGPI_DIST_LOOKAHEAD=0 turns it off)
+        block step k first updates only the block column of step k+1, then step k+1's panel work - diagonal
+        factorisation, panel solve and all its broadcasts - runs on a second stream while the rest of the trailing
+        update of step k runs on the main stream, so the xGMI transfers and the latency-bound panel hide behind
+        the MFMA work.  Every rank issues the same collectives in the same order in both modes."""
+        import os
+        g, be, nb = self.g, self.be, self.nb
+        if lookahead is None:
+            lookahead = os.environ.get('MGPI_DIST_LOOKAHEAD', '1') != '0'
+        side = be.side_backend() if lookahead else be
+        # panel buffers: two sets (step parity), allocated once on the main stream
+        bufs = [dict(lkk=be.empty(nb, nb), wrow=be.empty(max(self.mloc, 1), nb), wcol=be.empty(max(self.nloc, 1), nb),
+                     gather=be.empty(max(self.nloc, 1), nb)) for _ in range(2)]
+        info_first, logdiag = 0, 0.0
+
+        def note(pan):
+            nonlocal info_first, logdiag
+            if pan['info'] and not info_first:
+                info_first = pan['info']
+            logdiag += pan['logdiag']
+
+        ncols = len(self.col_blocks)
+        pan = self._panel(0, be, bufs[0])
+        note(pan)
+        for k in range(self.nblk):
+            nxt = k + 1 < self.nblk
+            j0 = pan['j0']
+            own_next = nxt and g.q == (k + 1) % g.Q              # the first local trailing column is block column k+1
+            if not lookahead or not nxt:
+                self._update(pan, j0, ncols, be)
+                if nxt:
+                    pan = self._panel(k + 1, be, bufs[(k + 1) % 2])
+                    note(pan)
+                continue
+            # (a) the block column of the next panel first
+            if own_next:
+                self._update(pan, j0, j0 + 1, be)
+            ready = be.record()
+            # (b) the rest of the trailing update, queued on the main stream
+            self._update(pan, j0 + 1 if own_next else j0, ncols, be)
+            # (c) meanwhile the next panel on the side stream (it touches block column k+1 only)
+            with be.on_side(ready):
+                nxt_pan = self._panel(k + 1, side, bufs[(k + 1) % 2])
+            be.join_side()
+            note(nxt_pan)
+            pan = nxt_pan
         # logdet and the first failing pivot, agreed by everyone
         if g.world > 1:
             s = self.be.from_numpy(np.array([logdiag]))

@@ -33,6 +33,20 @@ class NumpyTileBackend(object):
     def fence(self):
         pass
 
+    # the look-ahead's second stream: on the CPU everything simply runs in program order
+    def side_backend(self):
+        return self
+
+    def record(self):
+        return None
+
+    def on_side(self, after):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def join_side(self):
+        pass
+
     def cov(self, x_rows, x_cols, terms, out, n_rows_valid, n_cols_valid):
         out.zero_()
         if n_rows_valid and n_cols_valid:

@@ -17,8 +17,9 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, P, Q, n, d, m, nb, port, seed):
+def _worker(rank, world, P, Q, n, d, m, nb, port, seed, lookahead='1'):
     import sys
+    os.environ['MGPI_DIST_LOOKAHEAD'] = lookahead
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -90,6 +91,13 @@ def _worker(rank, world, P, Q, n, d, m, nb, port, seed):
 def test_block_cyclic_gloo(world, P, Q, n, nb):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, P, Q, n, 3, 21, nb, _free_port(), 100 + n), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize('world,P,Q,n,nb', [(2, 1, 2, 70, 8), (4, 2, 2, 150, 16)])
+def test_block_cyclic_gloo_without_lookahead(world, P, Q, n, nb):
+    """the plain schedule (panel, then the whole trailing update) stays available: MGPI_DIST_LOOKAHEAD=0"""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(world, P, Q, n, 3, 21, nb, _free_port(), 100 + n, '0'), nprocs=world, join=True)
 
 
 def test_choose_grid():
