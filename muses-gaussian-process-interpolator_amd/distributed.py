@@ -287,6 +287,8 @@ class DistributedGP(object):
         self.logdet = None
         self.alpha = None
         self.trailing_flops = 0.0     # algorithmic flops of this rank's trailing updates (bench.py roofline)
+        self.row_panels = None        # L[I][k] for the local block rows, every block step k (filled by factor)
+        self._row_panel_offset = None
 
     # -- index helpers ------------------------------------------------------------------------------------
     def _global_index(self, blocks):
@@ -351,7 +353,10 @@ class DistributedGP(object):
         nt = self.nloc - j0 * nb
         info, ld = 0, 0.0
         lkk = bufs['lkk']
-        wrow = bufs['wrow'][:max(mt, 1)]
+        # the row panel of step k lives in the persistent store (self.row_panels): the variance sweep reuses it, so
+        # L crosses xGMI once, not twice
+        off = self._row_panel_offset[k]
+        wrow = self.row_panels[off:off + max(mt, 1)]
         wcol = bufs['wcol'][:max(nt, 1)]
         # 1. diagonal block, down its process column
         if g.q == qk:
@@ -424,8 +429,17 @@ class DistributedGP(object):
             lookahead = os.environ.get('MGPI_DIST_LOOKAHEAD', '1') != '0'
         side = be.side_backend() if lookahead else be
         # panel buffers: two sets (step parity), allocated once on the main stream
-        bufs = [dict(lkk=be.empty(nb, nb), wrow=be.empty(max(self.mloc, 1), nb), wcol=be.empty(max(self.nloc, 1), nb),
-                     gather=be.empty(max(self.nloc, 1), nb)) for _ in range(2)]
+        bufs = [dict(lkk=be.empty(nb, nb), wcol=be.empty(max(self.nloc, 1), nb), gather=be.empty(max(self.nloc, 1), nb))
+                for _ in range(2)]
+        # persistent row panels: for every block step k the blocks L[I][k] of the local block rows I > k
+        # (sum_k (N - k nb)/P x nb doubles = 8 N^2 / (2P) bytes: 8.6 GB per rank at N = 65536 on 2 x 4)
+        offs, total = [], 0
+        for k in range(self.nblk):
+            offs.append(total)
+            total += max(self.mloc - self._first_local(self.row_blocks, k) * nb, 1)
+        self._row_panel_offset = offs
+        if self.row_panels is None or self.row_panels.shape[0] != total:
+            self.row_panels = be.empty(total, nb)
         info_first, logdiag = 0, 0.0
 
         def note(pan):
@@ -563,22 +577,20 @@ class DistributedGP(object):
             i0 = self._first_local(self.row_blocks, k)
             mt = self.mloc - i0 * nb
             # diagonal block to the whole process row pk, which solves its slice of block row k of V
-            vk = be.zeros(nb, per)
+            vk = be.empty(nb, per)
             if g.p == pk:
-                lkk = be.zeros(nb, nb)
+                lkk = be.empty(nb, nb)
                 if g.q == qk:
                     lkk.copy_(A[kr * nb:(kr + 1) * nb, kc * nb:(kc + 1) * nb])
                 self._bcast_row(lkk, pk, qk)
                 be.trsm_left(lkk, V[kr * nb:(kr + 1) * nb])
                 vk.copy_(V[kr * nb:(kr + 1) * nb])
             self._bcast_col(vk, g.q, pk)
-            # panel blocks L[I][k], I > k, along process rows
+            # panel blocks L[I][k], I > k: every rank kept its row panel of step k from the factorisation
+            # (self.row_panels), so the factor is NOT broadcast a second time
             if mt > 0:
-                wrow = be.zeros(mt, nb)
-                if g.q == qk:
-                    wrow.copy_(A[i0 * nb:, kc * nb:(kc + 1) * nb])
-                self._bcast_row(wrow, g.p, qk)
-                be.gemm_nn(V[i0 * nb:], wrow, vk)
+                off = self._row_panel_offset[k]
+                be.gemm_nn(V[i0 * nb:], self.row_panels[off:off + mt], vk)
         sq = be.colsq(V)
         if g.P > 1:
             t = be.from_numpy(sq)
