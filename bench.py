@@ -160,7 +160,13 @@ def cpu_baseline(seed=7):
     oracle.condition(kernel, nugget, xs, x, f)
     dt = time.perf_counter() - t0
     n = len(x)
-    return {'value': step_flops(n, m) / dt / 1e12, 'unit': 'TFLOP/s', 'cores': os.cpu_count(), 'kind': 'port',
+    try:    # the threads numpy's BLAS actually runs (its build caps them), not just the host's core count
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info() if p.get('user_api') == 'blas'] or [1])
+    except Exception:
+        threads = os.cpu_count()
+    return {'value': step_flops(n, m) / dt / 1e12, 'unit': 'TFLOP/s', 'cores': threads, 'host_cores': os.cpu_count(),
+            'kind': 'port',
             'sample': 'oracle.condition (numpy pair materialisation + LU inverse) at N=%d D=3 M=%d, same recipe; '
                       '%.1f s wall, algorithmic flops counted as for the GPU step' % (n, m, dt),
             'seconds': dt}
