@@ -42,6 +42,8 @@ extern "C" {
 /* kernel summand types (a1-a4 of SURVEY.md section 8) */
 #define MGPI_TERM_SE     0   /* SquaredExponentialKernel: sigma^2 exp(-sum_d (dx_d/l_d)^2), NO 1/2 (kernels.py:185) */
 #define MGPI_TERM_WHITE  1   /* WhiteNoiseKernel: sigma^2 [x1 == x2 exactly in every coordinate] (kernels.py:131) */
+#define MGPI_TERM_MATERN 2   /* MaternKernel: sigma^2 2^(1-o)/Gamma(o) r^o K_o(r), r = sqrt(2 o sum_d (dx_d/l_d)^2) (kernels.py:155-162);
+                              * at r == 0 the limit sigma^2 is returned where the reference evaluates 0*inf = NaN */
 
 #define MGPI_ERR_ARG     (-1)  /* bad argument (shape mismatch, D or nterms too large, null pointer) */
 #define MGPI_ERR_HIP     (-2)  /* HIP runtime error (incl. no device) */
@@ -52,9 +54,9 @@ extern "C" {
 typedef struct mgpi_kernel_desc {
     int32_t type;                 /* MGPI_TERM_* */
     int32_t reserved;
-    double  sigma;                /* params[0] of SE / WhiteNoise */
-    double  order;                /* Matern order (reserved) */
-    double  length[MGPI_MAX_D];   /* SE: params[1:1+D] */
+    double  sigma;                /* params[0] of SE / WhiteNoise, params[1] of Matern */
+    double  order;                /* Matern order o > 0 (params[0] of MaternKernel); unused otherwise */
+    double  length[MGPI_MAX_D];   /* SE: params[1:1+D]; Matern: params[2:2+D] */
 } mgpi_kernel_desc;
 
 typedef struct mgpi_ctx mgpi_ctx;   /* one GPU + its streams and workspace */

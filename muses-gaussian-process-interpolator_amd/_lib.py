@@ -5,7 +5,9 @@ numeric entry point raises.  The library is built in-tree by ``__graft_entry__.b
 ``make -C muses-gaussian-process-interpolator_amd/csrc``.
 """
 import ctypes
+import importlib.util
 import os
+import sys
 import threading
 
 import numpy as np
@@ -17,6 +19,7 @@ MAX_D = 16
 MAX_TERMS = 8
 TERM_SE = 0
 TERM_WHITE = 1
+TERM_MATERN = 2
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int64 = ctypes.c_int64
@@ -98,6 +101,27 @@ _lib = None
 _lib_lock = threading.Lock()
 
 
+def _share_torch_hip_runtime():
+    """One HIP/HSA runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so
+    and ask for them by the un-versioned file name, which the dynamic loader does not match against the
+    ``libamdhip64.so.7`` of /opt/rocm that libmgpi_hip.so would otherwise pull in.  A process that loaded this
+    library first and imports torch later (the multi-GPU driver, a user's own torch code) would then hold two HSA
+    runtimes, and the second one finds no GPU.  So when a torch wheel with a bundled runtime is installed, map ITS
+    runtime first - a dlopen of one file, torch itself is not imported - and libmgpi_hip.so binds to it by soname.
+    MGPI_HIP_RUNTIME=system keeps /opt/rocm's runtime (for processes that never import torch)."""
+    if 'torch' in sys.modules or os.environ.get('MGPI_HIP_RUNTIME', '') == 'system':
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        return
+    for root in (spec.submodule_search_locations or []) if spec is not None else []:
+        bundled = os.path.join(root, 'lib', 'libamdhip64.so')
+        if os.path.exists(bundled):
+            ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
+            return
+
+
 def load_library():
     """dlopen libmgpi_hip.so and declare every prototype; raises if the library was not built"""
     global _lib
@@ -106,6 +130,7 @@ def load_library():
             if not os.path.exists(LIB_PATH):
                 raise MgpiError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                                 '(there is no CPU fallback)' % LIB_PATH)
+            _share_torch_hip_runtime()
             lib = ctypes.CDLL(LIB_PATH)
             for name, (restype, argtypes) in _SIGNATURES.items():
                 fn = getattr(lib, name)   # AttributeError if the symbol is missing
@@ -139,15 +164,16 @@ def device_count():
 
 
 def make_terms(term_list):
-    """[(type, sigma, lengths), ...] -> (KernelDesc array, count)"""
+    """[(type, sigma, lengths[, order]), ...] -> (KernelDesc array, count)"""
     n = len(term_list)
     if not (1 <= n <= MAX_TERMS):
         raise ValueError('a kernel must flatten to between 1 and %d summands (got %d)' % (MAX_TERMS, n))
     arr = (KernelDesc * n)()
-    for i, (kind, sigma, lengths) in enumerate(term_list):
+    for i, term in enumerate(term_list):
+        kind, sigma, lengths = term[0], term[1], term[2]
         arr[i].type = int(kind)
         arr[i].sigma = float(sigma)
-        arr[i].order = 0.0
+        arr[i].order = float(term[3]) if len(term) > 3 else 0.0
         if len(lengths) > MAX_D:
             raise ValueError('at most %d dimensions are supported on the device path' % MAX_D)
         for k, val in enumerate(lengths):

@@ -401,15 +401,36 @@ int mgpi_make_terms(const mgpi_kernel_desc* terms, int nterms, int d, mgpi_terms
     out->nterms = nterms;
     out->d = d;
     for (int t = 0; t < nterms; ++t) {
-        MGPI_REQUIRE(terms[t].type == MGPI_TERM_SE || terms[t].type == MGPI_TERM_WHITE,
+        MGPI_REQUIRE(terms[t].type == MGPI_TERM_SE || terms[t].type == MGPI_TERM_WHITE || terms[t].type == MGPI_TERM_MATERN,
                      "kernel terms: term %d has unsupported type %d", t, terms[t].type);
         out->type[t] = terms[t].type;
         out->sig2[t] = terms[t].sigma * terms[t].sigma;          // sigma**2
-        if (terms[t].type == MGPI_TERM_SE)
+        if (terms[t].type == MGPI_TERM_SE || terms[t].type == MGPI_TERM_MATERN)
             for (int k = 0; k < d; ++k) {
                 // 1/length**2 ; a zero length gives inf, like the reference's division
                 out->inv_l2[t][k] = 1.0 / (terms[t].length[k] * terms[t].length[k]);
             }
+        if (terms[t].type == MGPI_TERM_MATERN) {
+            const double o = terms[t].order;
+            MGPI_REQUIRE(o > 0.0 && o <= 120.0, "kernel terms: Matern order %g outside (0, 120]", o);
+            const int nl = (int)(o + 0.5);
+            const double mu = o - nl;                             // |mu| <= 1/2
+            out->mat_nl[t] = nl;
+            out->mat_mu[t] = mu;
+            out->mat_order[t] = o;
+            out->mat_two_o[t] = 2.0 * o;
+            out->mat_norm[t] = pow(2.0, 1.0 - o) / tgamma(o);     // 2**(1-o)/gamma(o)  (kernels.py:162)
+            const double gampl = 1.0 / tgamma(1.0 + mu), gammi = 1.0 / tgamma(1.0 - mu);
+            out->mat_gampl[t] = gampl;
+            out->mat_gammi[t] = gammi;
+            out->mat_gam2[t] = 0.5 * (gammi + gampl);
+            if (fabs(mu) > 1e-3) {
+                out->mat_gam1[t] = (gammi - gampl) / (2.0 * mu);
+            } else {   // 1/Gamma(1+z) = 1 + c1 z + c2 z^2 + ...  =>  (rg(1-mu) - rg(1+mu)) / (2 mu) = -(c1 + c3 mu^2 + c5 mu^4)
+                const double c1 = 0.5772156649015329, c3 = -0.0420026350340952, c5 = -0.0421977345555443, m2 = mu * mu;
+                out->mat_gam1[t] = -(c1 + m2 * (c3 + m2 * c5));
+            }
+        }
     }
     return 0;
 }

@@ -4,6 +4,85 @@
 #pragma once
 #include "mgpi_internal.h"
 
+// Matern shape function  m(x) = 2^(1-o)/Gamma(o) * x^o * K_o(x),  x > 0, real order o = nl + mu (|mu| <= 1/2).
+// K_mu and K_{mu+1} come from Temme's series for x < 2 and Steed's continued fraction (CF2) above (Temme 1975; Press et
+// al. 6.7 describe the same scheme); the climb to order o uses the recurrence K_{v+1} = K_{v-1} + (2v/x) K_v - stable
+// upwards for K - written for T_v = x^v K_v:  T_{v+1} = x^2 T_{v-1} + 2v T_v.  T_v is positive, decreasing in x and
+// bounded by 2^(v-1) Gamma(v), so neither x^o (huge for far pairs) nor K_o (huge for near pairs) is ever formed on its
+// own.  The order-only constants (gam1, gam2, 1/Gamma(1 +- mu), norm = 2^(1-o)/Gamma(o)) come precomputed from the host.
+// Takes the role of  (2**(1-o)/gamma(o)) * diff**o * scipy.special.kv(o, diff)  in mgpi/kernels.py:162.
+__device__ __forceinline__ double mgpi_matern_shape(double x, int nl, double mu, double norm, double gam1, double gam2,
+                                                    double gampl, double gammi) {
+    if (nl > 0 && x < 1e-100) return 1.0;                    // 1 - m(x) = O(x^min(2o,2)): below one ulp here; K_{mu+1} would overflow
+    const double eps = 1e-16, mu2 = mu * mu, xi = 1.0 / x;
+    double kmu, k1;
+    if (x < 2.0) {
+        // Temme: f_0 = (mu pi / sin mu pi) [ cosh(sg) Gamma_1 + (sinh sg / sg) ln(2/x) Gamma_2 ],  sg = mu ln(2/x)
+        const double l2x = -log(0.5 * x);                    // ln(2/x)
+        const double sg = mu * l2x;
+        const double shc = (fabs(sg) < eps) ? 1.0 : sinh(sg) / sg;
+        const double pimu = 3.141592653589793 * mu;
+        const double fact = (fabs(pimu) < eps) ? 1.0 : pimu / sin(pimu);
+        double ff = fact * (gam1 * cosh(sg) + gam2 * shc * l2x);
+        double sum = ff;
+        const double ee = exp(sg);                           // (2/x)^mu
+        double p = 0.5 * ee / gampl;                         // p_0 = (1/2) (x/2)^-mu Gamma(1+mu)
+        double q = 0.5 / (ee * gammi);                       // q_0 = (1/2) (x/2)^+mu Gamma(1-mu)
+        double c = 1.0;
+        const double d = 0.25 * x * x;
+        double sum1 = p;
+        for (int i = 1; i <= 500; ++i) {
+            ff = (i * ff + p + q) / (i * (double)i - mu2);
+            c *= d / i;
+            p /= (i - mu);
+            q /= (i + mu);
+            const double del = c * ff;
+            sum += del;
+            sum1 += c * (p - i * ff);
+            if (fabs(del) < fabs(sum) * eps) break;
+        }
+        kmu = sum;
+        k1 = sum1 * 2.0 * xi;
+    } else {
+        double b = 2.0 * (1.0 + x), d = 1.0 / b, h = d, delh = d;
+        double q1 = 0.0, q2 = 1.0;
+        const double a1 = 0.25 - mu2;
+        double q = a1, c = a1, a = -a1;
+        double s = 1.0 + q * delh;
+        for (int i = 2; i <= 500; ++i) {
+            a -= 2 * (i - 1);
+            c = -a * c / i;
+            const double qnew = (q1 - b * q2) / a;
+            q1 = q2;
+            q2 = qnew;
+            q += c * qnew;
+            b += 2.0;
+            d = 1.0 / (b + a * d);
+            delh = (b * d - 1.0) * delh;
+            h += delh;
+            const double dels = q * delh;
+            s += dels;
+            if (fabs(dels) < fabs(s) * eps) break;
+        }
+        h = a1 * h;
+        kmu = sqrt(3.141592653589793 / (2.0 * x)) * exp(-x) / s;
+        k1 = kmu * (mu + x + 0.5 - h) * xi;
+    }
+    const double xm = pow(x, mu);
+    double t0 = xm * kmu;                                    // T_mu
+    if (nl > 0) {
+        double t1 = xm * x * k1;                             // T_{mu+1}
+        const double x2 = x * x;
+        for (int i = 1; i < nl; ++i) {
+            const double tn = x2 * t0 + 2.0 * (mu + i) * t1; // T_{mu+i+1}
+            t0 = t1;
+            t1 = tn;
+        }
+        t0 = t1;
+    }
+    return norm * t0;
+}
+
 // D > 0: compile-time dimensionality (registers, fully unrolled); D == 0: runtime t.d (<= MGPI_MAX_D)
 template <int D>
 __device__ __forceinline__ double mgpi_cov_entry(const mgpi_terms_dev& t, const double* __restrict__ a,
@@ -28,6 +107,17 @@ __device__ __forceinline__ double mgpi_cov_entry(const mgpi_terms_dev& t, const 
             for (int k = 0; k < ((D > 0) ? D : MGPI_MAX_D); ++k)
                 if (k < nd) r = __dadd_rn(r, __dmul_rn(diff2[k], t.inv_l2[s][k]));   // sum_d (x1-x2)**2/length_d**2, left to right, no fma contraction
             val = __dadd_rn(val, __dmul_rn(t.sig2[s], exp(-r)));   // sigma**2 * exp(-r), rounded product then add
+        } else if (t.type[s] == MGPI_TERM_MATERN) {
+            double r = 0.0;
+#pragma unroll
+            for (int k = 0; k < ((D > 0) ? D : MGPI_MAX_D); ++k)
+                if (k < nd) r = __dadd_rn(r, __dmul_rn(diff2[k], t.inv_l2[s][k]));
+            const double diff = sqrt(t.mat_two_o[s]) * sqrt(r);    // (2*o)**0.5 * sum(...)**0.5   (kernels.py:161)
+            double m = 1.0;                                        // r -> 0 limit of the bracket below (the reference: NaN)
+            if (diff > 0.0)
+                m = mgpi_matern_shape(diff, t.mat_nl[s], t.mat_mu[s], t.mat_norm[s], t.mat_gam1[s], t.mat_gam2[s],
+                                      t.mat_gampl[s], t.mat_gammi[s]);
+            val = __dadd_rn(val, __dmul_rn(t.sig2[s], m));
         } else {
             val = __dadd_rn(val, same ? t.sig2[s] : 0.0);        // sigma**2 * all(x1 == x2)
         }

@@ -82,7 +82,11 @@ struct mgpi_terms_dev {
     int d;
     int type[MGPI_MAX_TERMS];
     double sig2[MGPI_MAX_TERMS];                    // sigma**2              (kernels.py:131,185)
-    double inv_l2[MGPI_MAX_TERMS][MGPI_MAX_D];      // 1/length_d**2         (kernels.py:185)
+    double inv_l2[MGPI_MAX_TERMS][MGPI_MAX_D];      // 1/length_d**2         (kernels.py:185,161)
+    // Matern terms: order o = nl + mu with |mu| <= 1/2, and the x-independent constants of Temme's series
+    int mat_nl[MGPI_MAX_TERMS];
+    double mat_mu[MGPI_MAX_TERMS], mat_two_o[MGPI_MAX_TERMS], mat_norm[MGPI_MAX_TERMS], mat_order[MGPI_MAX_TERMS];
+    double mat_gam1[MGPI_MAX_TERMS], mat_gam2[MGPI_MAX_TERMS], mat_gampl[MGPI_MAX_TERMS], mat_gammi[MGPI_MAX_TERMS];
 };
 int mgpi_make_terms(const mgpi_kernel_desc* terms, int nterms, int d, mgpi_terms_dev* out);
 

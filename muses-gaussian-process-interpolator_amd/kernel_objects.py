@@ -148,14 +148,20 @@ class WhiteNoiseKernel(Kernel):
 
 
 class MaternKernel(NDKernel):
-    """Matern(order, sigma, *lengths) (mgpi/kernels.py:135-162): parameter container only.
-    The reference's evaluation is NaN at zero separation and a device Matern is a
-    "next" row; nothing here falls back to the CPU, so cov()/terms() raise."""
+    """Matern(order, sigma, *lengths) (mgpi/kernels.py:135-162):
+        r = sqrt(2 order sum_d ((x1_d - x2_d)/length_d)**2);  cov = sigma**2 2**(1-order)/Gamma(order) r**order K_order(r)
+    evaluated on the GPU for any real order in (0, 120] (K_order by Temme's series / Steed's continued fraction,
+    csrc/cov_device.h, in the role of scipy.special.kv).  Deliberate deviation: at zero separation the reference
+    computes 0**order * K(0) = 0 * inf = NaN (SURVEY.md section 0), which makes every source-source matrix unusable;
+    here r == 0 gives the limit sigma**2."""
 
     _leading = ('order', 'sigma')
 
     def __init__(self, order, sigma, *lengths):
         NDKernel.__init__(self, order, sigma, *lengths)
+
+    def terms(self):
+        return [(_lib.TERM_MATERN, float(self.params[1]), tuple(float(v) for v in self.params[2:]), float(self.params[0]))]
 
 
 class SquaredExponentialKernel(MaternKernel):
@@ -167,7 +173,7 @@ class SquaredExponentialKernel(MaternKernel):
     def __init__(self, sigma, *lengths):
         NDKernel.__init__(self, sigma, *lengths)
 
-    def terms(self):
+    def terms(self):                     # overrides MaternKernel.terms: params are (sigma, lengths...), no order
         return [(_lib.TERM_SE, float(self.params[0]), tuple(float(v) for v in self.params[1:]))]
 
 

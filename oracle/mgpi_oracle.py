@@ -24,6 +24,7 @@ import numpy as np
 # kernel term type codes: the same integers as include/mgpi_hip.h
 TERM_SE = 0
 TERM_WHITE = 1
+TERM_MATERN = 2
 
 #-------------------------------------------------
 # kernel terms: a kernel is a list of (type, sigma, lengths) tuples that are summed
@@ -38,18 +39,41 @@ def term_white(sigma):
     return (TERM_WHITE, float(sigma), np.zeros(0, dtype=float))
 
 
+def term_matern(order, sigma, *lengths):
+    """(type, sigma, lengths, order): the argument order of MaternKernel(order, sigma, *lengths), kernels.py:139"""
+    return (TERM_MATERN, float(sigma), np.asarray(lengths, dtype=float), float(order))
+
+
+# The reference's Matern is 0**o * K_o(0) = 0 * inf = NaN at zero separation (SURVEY.md section 0), which makes
+# every K(x,x) unusable.  With MATERN_ZERO_LIMIT = True the oracle substitutes the r -> 0 limit sigma**2 there -
+# the product's documented deviation - so that full solves with a Matern term can be cross-checked; every entry at
+# non-zero separation is the reference's formula either way.  Tests set this flag explicitly when they need it.
+MATERN_ZERO_LIMIT = False
+
+
 def paired_cov(terms, x1, x2):
     """row-paired covariance, x1 and x2 both (P, D) -> (P,)
 
-    SE:    mgpi/kernels.py:180-185   sigma**2 * exp(-sum((x1-x2)**2/lengths**2, axis=1))   (no 1/2)
-    white: mgpi/kernels.py:128-131   sigma**2 * all(x1==x2, axis=1)
-    sum:   mgpi/kernels.py:287-293   ans = 0.0; ans += term   (left to right)
+    SE:     mgpi/kernels.py:180-185   sigma**2 * exp(-sum((x1-x2)**2/lengths**2, axis=1))   (no 1/2)
+    white:  mgpi/kernels.py:128-131   sigma**2 * all(x1==x2, axis=1)
+    Matern: mgpi/kernels.py:155-162   diff = (2o)**0.5 * sum(...)**0.5; s**2 * (2**(1-o)/gamma(o)) * diff**o * kv(o, diff)
+    sum:    mgpi/kernels.py:287-293   ans = 0.0; ans += term   (left to right)
     """
     x1 = np.asarray(x1, dtype=float)
     x2 = np.asarray(x2, dtype=float)
     total = 0.0
-    for kind, sigma, lengths in terms:
-        if kind == TERM_SE:
+    for term in terms:
+        kind, sigma, lengths = term[0], term[1], term[2]
+        if kind == TERM_MATERN:
+            from scipy.special import gamma as _gamma, kv as _bessel_k      # kernels.py:15-16
+            o = term[3]
+            with np.errstate(invalid='ignore', over='ignore'):
+                diff = (2 * o)**0.5 * np.sum((x1 - x2)**2 / lengths**2, axis=1)**0.5
+                val = sigma**2 * (2**(1 - o) / _gamma(o)) * diff**o * _bessel_k(o, diff)
+            if MATERN_ZERO_LIMIT:
+                val = np.where(diff == 0, sigma**2, val)
+            total = total + val
+        elif kind == TERM_SE:
             total = total + sigma**2 * np.exp(-np.sum((x1 - x2)**2 / lengths**2, axis=1))
         elif kind == TERM_WHITE:
             total = total + sigma**2 * np.all(x1 == x2, axis=1)

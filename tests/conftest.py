@@ -16,8 +16,30 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
-def golden_names():
+def _all_golden():
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, '*.npz')))
+
+
+def golden_names():
+    """the full-path fixtures (kernel matrices + compress/predict/condition/loglikelihood outputs)"""
+    return [n for n in _all_golden() if not n.startswith('matern_')]
+
+
+def matern_names():
+    """kernel-matrix-only fixtures of the reference's MaternKernel (its K(x,x) has a NaN diagonal)"""
+    return [n for n in _all_golden() if n.startswith('matern_')]
+
+
+def matern_terms(g, flavour):
+    """a matern_* fixture -> oracle term tuples (flavour 'oracle') or an mgpi_amd kernel object ('product')"""
+    order, sigma, lengths = float(g['order']), float(g['sigma']), [float(v) for v in g['lengths']]
+    if flavour == 'oracle':
+        from oracle import mgpi_oracle as oracle
+        return [oracle.term_matern(order, sigma, *lengths)] + oracle_terms(g, 'extra')
+    import mgpi_amd as mgpi
+    first = mgpi.MaternKernel(order, sigma, *lengths)
+    rest = product_kernel(g, 'extra')
+    return first if rest is None else first + rest
 
 
 def load_golden(name):

@@ -97,6 +97,22 @@ def run(name, x, f, xs, kernel, nugget, full_cov=True, store_K=True):
           (name, len(x), len(xs), ndim, out['cond_K'], time.time() - t0, os.path.getsize(path) / 1e3))
 
 
+def run_matern(name, x, xs, order, sigma, lengths, extra=()):
+    """Matern kernel matrices from the reference: K(x,x) (NaN on the diagonal - the reference's 0*inf, SURVEY.md
+    section 0) and K(xs,x) with no coincident points.  `extra`: further ('se'|'white', ...) summands."""
+    kobj = mgpi.MaternKernel(order, sigma, *lengths)
+    objs = [kobj] + [build([t]) for t in extra]
+    kern = objs[0] if len(objs) == 1 else mgpi.CombinedKernel(*objs)
+    with np.errstate(invalid='ignore'):
+        K = mgpi.Interpolator._x2cov(x, x, kern)
+        Ks = mgpi.Interpolator._x2cov(xs, x, kern)
+    out = dict(x=x, xs=xs, K=K, Ks=Ks, order=np.array(order), sigma=np.array(sigma), lengths=np.array(lengths, dtype=float))
+    out.update(encode(list(extra), x.shape[1], 'extra'))
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('%-28s N=%-5d M=%-5d D=%d order=%g  NaN entries in K: %d' % (name, len(x), len(xs), x.shape[1], order, np.isnan(K).sum()))
+
+
 def smooth(x):
     """a smooth scalar field on [0,1]^D-ish inputs"""
     x = np.asarray(x, dtype=float)
@@ -137,6 +153,20 @@ def main():
     # no white noise at all, well separated points (K well conditioned on its own)
     x = rng.random((30, 2)) * 4.0
     run('toy_nonugget', x, smooth(x), rng.random((6, 2)) * 4.0, [('se', 1.0, (0.5, 0.5))], [])
+
+    # Matern (kernels.py:135-162): etc/example-interpolator.ini's Kernel3 (order 2, sigma 0.1, lengths 15 10) on a
+    # (muB, T)-like scatter, half-integer and non-integer orders, tiny and huge separations
+    rngm = np.random.default_rng(11)
+    xm = np.transpose([rngm.uniform(0, 150, 60), rngm.uniform(30, 100, 60)])
+    xsm = np.transpose([rngm.uniform(0, 150, 25), rngm.uniform(30, 100, 25)])
+    xsm[0] = xm[0] + [1e-7, 0.0]                       # nearly coincident
+    xsm[1] = xm[1] + [400.0, 300.0]                    # far: K_o underflows towards 0
+    run_matern('matern_o2_ini', xm, xsm, 2, 0.1, (15., 10.))
+    run_matern('matern_o0p5', xm, xsm, 0.5, 1.3, (20., 12.))
+    run_matern('matern_o1p5', xm, xsm, 1.5, 0.7, (20., 12.))
+    run_matern('matern_o2p7_plus_se', xm, xsm, 2.7, 0.7, (25., 15.), extra=[('se', 0.1, (10., 20.)), ('white', 1e-3)])
+    x3 = rngm.random((40, 3))
+    run_matern('matern_o1_d3', x3, rngm.random((12, 3)), 1, 2.0, (0.3, 0.4, 0.5))
 
     # (2) uiuc-test style: 2-D grid, checkerboard split, sigma = 1.5 std f, ell = 2*spacing,
     #     white sigma/1000 inside the CombinedKernel (test/uiuc/uiuc-test:114-189); mean subtracted (:203)

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import mgpi_amd as mgpi
-from conftest import golden_names, load_golden, mean_tol, oracle_terms, prior_var, product_kernel, relmax, var_tol
+from conftest import golden_names, load_golden, matern_names, matern_terms, mean_tol, oracle_terms, prior_var, product_kernel, relmax, var_tol
 from oracle import mgpi_oracle as oracle
 
 pytestmark = pytest.mark.gpu
@@ -266,3 +266,101 @@ def test_optimize_kernel_recovers_a_better_likelihood():
     after = it.loglikelihood(x, f)
     assert after >= before - 1e-9
     assert out.dtype.names == ('sigma', 'length0') and out['sigma'][0] == k.params[0] and out['length0'][0] == k.params[1]
+
+
+#-------------------------------------------------
+# Matern (kernels.py:135-162): the device evaluates K_order itself (Temme / Steed), scipy.special.kv is the checker
+
+
+@pytest.mark.parametrize('name', matern_names())
+def test_matern_golden(name):
+    """every entry at non-zero separation against the reference's own output (rtol 2e-12: K_order by series /
+    continued fraction to ~1e-13, and the fixtures hold separations 1e-7 ell .. 50 ell); the zero-separation
+    diagonal, NaN in the reference, is the limit sigma**2 (documented deviation)"""
+    g = load_golden(name)
+    kern = matern_terms(g, 'product')
+    K = mgpi.Interpolator._x2cov(g['x'], g['x'], kern)
+    Ks = mgpi.Interpolator._x2cov(g['xs'], g['x'], kern)
+    off = ~np.eye(len(K), dtype=bool)
+    np.testing.assert_allclose(K[off], g['K'][off], rtol=2e-12, atol=1e-300)
+    np.testing.assert_allclose(Ks, g['Ks'], rtol=2e-12, atol=1e-300)
+    extra = sum(float(s)**2 for s in g['extra_sigmas'])
+    np.testing.assert_allclose(np.diag(K), float(g['sigma'])**2 + extra, rtol=1e-15)
+    np.testing.assert_array_equal(K, K.T)
+    # row-paired entry point (Kernel.cov) agrees with the matrix build bit for bit
+    i, j = np.arange(len(g['xs'])), (np.arange(len(g['xs'])) * 7) % len(g['x'])
+    np.testing.assert_array_equal(kern.cov(g['xs'][i], g['x'][j]), Ks[i, j])
+
+
+@pytest.mark.parametrize('order', [0.05, 0.3, 0.5, 0.999, 1.0, 1.0001, 1.5, 2.0, 2.5, 3.49, 3.5, 3.51, 6.0, 12.3, 40.0, 120.0])
+def test_matern_orders_against_oracle(order):
+    """separations from 1e-9 to 300 length scales, both branches of K_order (x < 2 series, x >= 2 continued fraction)
+    and the upward recurrence.  AMOS behind scipy.special.kv flushes K to exactly zero from x ~ 650 on, where
+    r**order K(r) is still representable and the device returns it: those points only have to be tiny"""
+    rng = np.random.default_rng(int(order * 1000))
+    r = np.concatenate([10.0**rng.uniform(-9, 2.5, 3000), np.linspace(1.9, 2.1, 41) / np.sqrt(2 * order)])
+    x1 = rng.standard_normal((len(r), 3))
+    u = rng.standard_normal((len(r), 3))
+    u /= np.linalg.norm(u, axis=1)[:, None]
+    lengths = (0.7, 1.3, 2.1)
+    x2 = x1 + u * r[:, None] * np.array(lengths)
+    got = mgpi.MaternKernel(order, 1.7, *lengths).cov(x1, x2)
+    want = oracle.paired_cov([oracle.term_matern(order, 1.7, *lengths)], x1, x2)
+    ok = np.isfinite(want)                  # kv overflows to inf (times 0 -> NaN) for tiny separations at large order
+    assert ok.mean() > 0.25          # order 120: kv itself overflows below x ~ 1
+    flushed = ok & (want == 0) & (np.sqrt(2 * order) * r > 600)
+    np.testing.assert_allclose(got[ok & ~flushed], want[ok & ~flushed], rtol=5e-12, atol=1e-300)
+    assert np.all(got[flushed] < 1e-150)
+    assert np.all(np.isfinite(got)) and np.all(got <= 1.7**2 * (1 + 1e-12)) and np.all(got >= 0)
+    # where the reference's expression gives up (inf * 0): near pairs follow the small-separation limit sigma**2, the
+    # rest is checked in log space with the exponentially scaled kve where that is finite
+    x = np.sqrt(2 * order) * r
+    near = ~ok & (x < 1e-3)
+    assert np.all(np.abs(got[near] - 1.7**2) < 1e-5 * 1.7**2)
+    from scipy.special import gammaln, kve
+    with np.errstate(all='ignore'):
+        logm = (1 - order) * np.log(2) - gammaln(order) + order * np.log(x) + np.log(kve(order, x)) - x
+    rest = ~ok & ~near & np.isfinite(logm) & (logm > -600) & (x < 700)    # beyond: exp(-x) underflows, the device returns 0
+    np.testing.assert_allclose(got[rest], 1.7**2 * np.exp(logm[rest]), rtol=1e-10)
+
+
+def test_matern_half_integer_closed_forms():
+    """order 1/2: sigma**2 exp(-r); 3/2: (1+r) exp(-r); 5/2: (1 + r + r**2/3) exp(-r)   with r = sqrt(2 order) d"""
+    rng = np.random.default_rng(5)
+    x1, x2 = rng.random((500, 2)), rng.random((500, 2))
+    d = np.sqrt(np.sum(((x1 - x2) / np.array([0.2, 0.4]))**2, axis=1))
+    for order, poly in [(0.5, lambda r: 1.0), (1.5, lambda r: 1 + r), (2.5, lambda r: 1 + r + r * r / 3)]:
+        r = np.sqrt(2 * order) * d
+        got = mgpi.MaternKernel(order, 2.0, 0.2, 0.4).cov(x1, x2)
+        np.testing.assert_allclose(got, 4.0 * poly(r) * np.exp(-r), rtol=1e-12)
+
+
+def test_matern_full_path_like_the_example_ini():
+    """etc/example-interpolator.ini: SE(0.1; 10, 20) + WhiteNoise + Matern(2, 0.1; 15, 10) - unusable in the
+    reference (NaN diagonal).  With the zero-separation limit it is a valid kernel: check the whole path against the
+    oracle run with the same convention (MATERN_ZERO_LIMIT, oracle header)."""
+    rng = np.random.default_rng(21)
+    x = np.transpose([rng.uniform(0, 150, 400), rng.uniform(30, 100, 400)])
+    xs = np.transpose([rng.uniform(0, 150, 90), rng.uniform(30, 100, 90)])
+    f = 0.05 * np.tanh((x[:, 1] - 60.0) / 20.0) + 0.01 * np.sin(x[:, 0] / 30.0)
+    kern = mgpi.SquaredExponentialKernel(0.1, 10, 20) + mgpi.MaternKernel(2, 0.1, 15, 10)
+    interp = mgpi.Interpolator(kern, nugget=mgpi.WhiteNoiseKernel(1e-3))
+    kt = [oracle.term_se(0.1, 10, 20), oracle.term_matern(2, 0.1, 15, 10)]
+    nt = [oracle.term_white(1e-3)]
+    oracle.MATERN_ZERO_LIMIT = True
+    try:
+        cond = np.linalg.cond(oracle.x2cov(kt + nt, x, x))
+        want_mean, want_cov = oracle.condition(kt, nt, xs, x, f)
+        want_ll = oracle.loglikelihood(kt, nt, x, f)
+    finally:
+        oracle.MATERN_ZERO_LIMIT = False
+    mean, cov = interp.condition(xs, x, f)
+    assert relmax(mean, want_mean) < mean_tol(cond)
+    assert np.max(np.abs(cov - want_cov)) < var_tol(cond) * 0.02
+    assert abs(interp.loglikelihood(x, f) - want_ll) < mean_tol(cond) * abs(want_ll)
+
+
+def test_matern_order_limits():
+    for bad in [0.0, -1.0, 120.5, np.nan]:
+        with pytest.raises((ValueError, RuntimeError, AssertionError)):
+            mgpi.MaternKernel(bad, 1.0, 1.0).cov(np.zeros((1, 1)), np.ones((1, 1)))

@@ -135,9 +135,16 @@ def test_interpolator_holds_kernel_and_nugget():
     assert it.nugget.params[0] == 0.2
 
 
-def test_matern_has_no_silent_cpu_path():
-    with pytest.raises(NotImplementedError):
-        mgpi.MaternKernel(2, 1.0, 1.0).terms()
+def test_matern_terms_carry_the_order():
+    """MaternKernel(order, sigma, *lengths) -> one device term descriptor; the SE subclass drops the order"""
+    (kind, sigma, lengths, order), = mgpi.MaternKernel(2.5, 0.1, 15, 10).terms()
+    assert (kind, sigma, lengths, order) == (mgpi._lib.TERM_MATERN, 0.1, (15.0, 10.0), 2.5)
+    arr, n = mgpi._lib.make_terms(mgpi.MaternKernel(2.5, 0.1, 15, 10).terms())
+    assert n == 1 and arr[0].type == 2 and arr[0].order == 2.5 and arr[0].length[1] == 10.0
+    (kind, sigma, lengths), = mgpi.SquaredExponentialKernel(0.1, 15, 10).terms()
+    assert kind == mgpi._lib.TERM_SE
+    mixed = mgpi.SquaredExponentialKernel(0.1, 10, 20) + mgpi.WhiteNoiseKernel(1e-4) + mgpi.MaternKernel(2, 0.1, 15, 10)
+    assert [t[0] for t in mixed.terms()] == [0, 1, 2]      # etc/example-interpolator.ini's three kernels
 
 
 def test_make_terms_limits():

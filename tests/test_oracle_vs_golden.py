@@ -7,7 +7,7 @@ K entries bit-exact; solves within a few ulp * cond(K)."""
 import numpy as np
 import pytest
 
-from conftest import golden_names, load_golden, mean_tol, oracle_terms, prior_var, relmax, var_tol
+from conftest import golden_names, load_golden, matern_names, matern_terms, mean_tol, oracle_terms, prior_var, relmax, var_tol
 from oracle import mgpi_oracle as oracle
 
 NAMES = golden_names()
@@ -91,3 +91,25 @@ def test_known_answers():
     mean, cov = oracle.condition(se, [oracle.term_white(0.1)], [[0.3]], [[0.3]], [1.5])
     assert abs(mean[0] - 1.5 * 4.0 / kk) < 1e-15
     assert abs(cov[0, 0] - (4.0 - 16.0 / kk)) < 1e-14
+
+
+@pytest.mark.parametrize('name', matern_names())
+def test_oracle_matern_matches_reference(name):
+    """kernels.py:155-162 incl. the reference's NaN at zero separation; and the flagged zero-limit variant
+    changes those entries only"""
+    g = load_golden(name)
+    terms = matern_terms(g, 'oracle')
+    K = oracle.x2cov(terms, g['x'], g['x'])
+    assert np.array_equal(K, g['K'], equal_nan=True)
+    assert np.array_equal(oracle.x2cov(terms, g['xs'], g['x']), g['Ks'])
+    assert np.isnan(np.diag(g['K'])).all() and np.isnan(g['K']).sum() == len(g['x'])
+    assert np.isfinite(g['Ks']).all()
+    oracle.MATERN_ZERO_LIMIT = True
+    try:
+        K1 = oracle.x2cov(terms, g['x'], g['x'])
+    finally:
+        oracle.MATERN_ZERO_LIMIT = False
+    off = ~np.eye(len(K), dtype=bool)
+    assert np.array_equal(K1[off], g['K'][off])
+    extra = sum(float(s)**2 for s in g['extra_sigmas'])     # SE and white summands are sigma**2 on the diagonal
+    np.testing.assert_allclose(np.diag(K1), float(g['sigma'])**2 + extra, rtol=1e-15)
