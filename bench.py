@@ -128,11 +128,11 @@ class DistributedStep(object):
     """one GP across all ranks: block-cyclic build + factor + solve + mean + variance (inputs replicated on the
     hosts, K / L / V distributed in HBM)"""
 
-    def __init__(self, torch, dist, x, f, xs, ell):
+    def __init__(self, torch, dist, x, f, xs, ell, host_staged=False):
         import mgpi_amd as mgpi
         from mgpi_amd.distributed import DistributedGP, HipTileBackend, ProcessGrid
         self.ctx = mgpi.default_context()
-        self.grid = ProcessGrid(dist)
+        self.grid = ProcessGrid(dist, host_staged=host_staged)
         self.be = HipTileBackend(torch, self.ctx)
         k = mgpi.SquaredExponentialKernel(1.0, *ell)
         nug = mgpi.WhiteNoiseKernel(1e-2)
@@ -194,6 +194,11 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    # developer switch (rehearsal on a one-GPU box): all ranks share GPU 0, gloo with host-staged collectives,
+    # optional small problem MGPI_BENCH_SIDE=16x16x16; the numbers mean nothing, the code path is the N>1 one
+    share_gpu = world > 1 and os.environ.get('MGPI_BENCH_SHARE_GPU') == '1'
+    if share_gpu:
+        local_rank = 0
     os.environ.setdefault('MGPI_DEVICE', str(local_rank))
 
     dist = None
@@ -207,7 +212,10 @@ def main():
         torch.cuda.set_device(local_rank)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if share_gpu:
+            dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     if not distributed:
         n_side, d, m, seed = WORKLOADS[args.workload]
@@ -217,8 +225,11 @@ def main():
     else:
         assert force_dist or world in MULTI, 'supported GPU counts: 1, %s' % sorted(MULTI)
         n_side, d, m, seed = MULTI[2 if force_dist else world]
+        if share_gpu and os.environ.get('MGPI_BENCH_SIDE'):
+            n_side = tuple(int(v) for v in os.environ['MGPI_BENCH_SIDE'].split('x'))
+            d = len(n_side)
         x, f, xs, ell = make_inputs(n_side, m, seed)           # the same seed on every rank: replicated inputs
-        step = DistributedStep(torch, dist, x, f, xs, ell)
+        step = DistributedStep(torch, dist, x, f, xs, ell, host_staged=share_gpu)
         name = 'C4' if world == 8 else 'C3 scaled by %d^(1/3)' % world
         par = '2-D block-cyclic %dx%d, nb=%d, RCCL panel broadcasts' % (step.grid.P, step.grid.Q, NB)
     n = len(x)
@@ -241,7 +252,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if share_gpu else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -41,9 +41,13 @@ def choose_grid(world):
 class ProcessGrid(object):
     """rank <-> (p, q) on a P x Q grid (row-major), with one process group per grid row and per grid column"""
 
-    def __init__(self, dist, P=None, Q=None, always_communicate=False):
+    def __init__(self, dist, P=None, Q=None, always_communicate=False, host_staged=False):
         self.dist = dist
         self.always = bool(always_communicate)   # tests: issue the collectives even inside size-1 groups
+        # rehearsal transport: device buffers cross through host copies, so that several ranks can SHARE one GPU
+        # under gloo (RCCL refuses two ranks on one device).  tests/test_gpu_distributed.py uses it to run the real
+        # multi-rank tile distribution with the HIP backend on a one-GPU box; never set on a multi-GPU launch.
+        self.host_staged = bool(host_staged)
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         if P is None:
@@ -58,26 +62,51 @@ class ProcessGrid(object):
     def rank_of(self, p, q):
         return p * self.Q + q
 
+    def _issue(self, collective, tensor):
+        if self.host_staged and getattr(tensor, 'is_cuda', False):
+            host = tensor.cpu()                  # waits for the producing kernels on the current stream
+            collective(host)
+            tensor.copy_(host)
+        else:
+            collective(tensor)
+
     def bcast_row(self, tensor, p, src_q):
         """broadcast inside grid row p from column src_q (only ranks of that row call this)"""
         if self.Q > 1 or self.always:
-            self.dist.broadcast(tensor, src=self.rank_of(p, src_q), group=self.row_groups[p])
+            self._issue(lambda t: self.dist.broadcast(t, src=self.rank_of(p, src_q), group=self.row_groups[p]), tensor)
 
     def bcast_col(self, tensor, q, src_p):
         if self.P > 1 or self.always:
-            self.dist.broadcast(tensor, src=self.rank_of(src_p, q), group=self.col_groups[q])
+            self._issue(lambda t: self.dist.broadcast(t, src=self.rank_of(src_p, q), group=self.col_groups[q]), tensor)
 
     def bcast_world(self, tensor, src):
         if self.world > 1 or self.always:
-            self.dist.broadcast(tensor, src=src)
+            self._issue(lambda t: self.dist.broadcast(t, src=src), tensor)
 
     def reduce_row(self, tensor, p, dst_q):
         if self.Q > 1 or self.always:
-            self.dist.reduce(tensor, dst=self.rank_of(p, dst_q), op=self.dist.ReduceOp.SUM, group=self.row_groups[p])
+            self._issue(lambda t: self.dist.reduce(t, dst=self.rank_of(p, dst_q), op=self.dist.ReduceOp.SUM,
+                                                   group=self.row_groups[p]), tensor)
 
     def reduce_col(self, tensor, q, dst_p):
         if self.P > 1 or self.always:
-            self.dist.reduce(tensor, dst=self.rank_of(dst_p, q), op=self.dist.ReduceOp.SUM, group=self.col_groups[q])
+            self._issue(lambda t: self.dist.reduce(t, dst=self.rank_of(dst_p, q), op=self.dist.ReduceOp.SUM,
+                                                   group=self.col_groups[q]), tensor)
+
+    def all_reduce(self, tensor, op='sum', col=None):
+        """all-reduce over the world, or inside process column `col`"""
+        red = self.dist.ReduceOp.SUM if op == 'sum' else self.dist.ReduceOp.MAX
+        group = None if col is None else self.col_groups[col]
+        self._issue(lambda t: self.dist.all_reduce(t, op=red, group=group), tensor)
+
+    def all_gather(self, parts, mine):
+        if self.host_staged and getattr(mine, 'is_cuda', False):
+            host = [t.cpu() for t in parts]
+            self.dist.all_gather(host, mine.cpu())
+            for dst, src in zip(parts, host):
+                dst.copy_(src)
+        else:
+            self.dist.all_gather(parts, mine)
 
 
 class HipTileBackend(object):
@@ -476,10 +505,10 @@ class DistributedGP(object):
         # logdet and the first failing pivot, agreed by everyone
         if g.world > 1:
             s = self.be.from_numpy(np.array([logdiag]))
-            g.dist.all_reduce(s, op=g.dist.ReduceOp.SUM)
+            g.all_reduce(s, 'sum')
             logdiag = float(self.be.to_numpy(s)[0])
             m = self.be.from_numpy(np.array([float(-info_first) if info_first else -1e300]))
-            g.dist.all_reduce(m, op=g.dist.ReduceOp.MAX)      # max of (-info) = smallest failing pivot
+            g.all_reduce(m, 'max')                            # max of (-info) = smallest failing pivot
             worst = float(self.be.to_numpy(m)[0])
             info_first = int(-worst) if worst > -1e299 else 0
         if info_first:
@@ -550,7 +579,7 @@ class DistributedGP(object):
             return part[:m]
         mine = be.from_numpy(part)
         parts = [be.zeros(per) for _ in range(g.world)]
-        g.dist.all_gather(parts, mine)
+        g.all_gather(parts, mine)
         return np.concatenate([be.to_numpy(t) for t in parts])[:m]
 
     def variance(self, target_x):
@@ -594,7 +623,7 @@ class DistributedGP(object):
         sq = be.colsq(V)
         if g.P > 1:
             t = be.from_numpy(sq)
-            g.dist.all_reduce(t, op=g.dist.ReduceOp.SUM, group=g.col_groups[g.q])
+            g.all_reduce(t, 'sum', col=g.q)
             sq = be.to_numpy(t)
         var_q = np.zeros(per)
         if hi > lo:
@@ -603,7 +632,7 @@ class DistributedGP(object):
             return var_q[:m]
         mine = be.from_numpy(var_q)
         parts = [be.zeros(per) for _ in range(g.world)]
-        g.dist.all_gather(parts, mine)
+        g.all_gather(parts, mine)
         # ranks of one process column hold identical slices; take grid row 0
         out = np.concatenate([be.to_numpy(parts[g.rank_of(0, qq)]) for qq in range(g.Q)])
         return out[:m]

@@ -1,8 +1,9 @@
 """BASELINE.json config 0 (C1): the INI plumbing - parse_table on an ascii table with prior cuts and a row-stride
 downsample, parse_interpolator by class name - on a synthetic stand-in for the reference's missing data file
 (etc/uiuc/equation_of_state.csv.gz is listed in .MISSING_LARGE_BLOBS).  Option names, prior bounds
-and kernel values are those of etc/example-ascii-data.ini and etc/example-interpolator.ini (Matern term dropped:
-it is NaN at zero distance in the reference)."""
+and kernel values are those of etc/example-ascii-data.ini and etc/example-interpolator.ini.  The golden C1 fixture
+drops that file's Matern term (it is NaN at zero distance in the reference); the last test
+runs all three kernels with the product's zero-separation limit."""
 import os
 
 import numpy as np
@@ -101,3 +102,45 @@ def test_c1_end_to_end_from_ini_files(tmp_path):
     assert relmax(mean, g['cond_mean']) < mean_tol(cond)
     assert np.max(np.abs(cov - g['cond_cov'])) / prior_var(g) < var_tol(cond)
     assert relmax(it.predict(g['xs'], x, it.compress(x, f)), g['predict_mean']) < mean_tol(cond)
+
+
+MATERN_SECTION = """
+[Kernel3]
+type = MaternKernel
+order = 2
+sigma = 1e-1
+length0 = 15
+length1 = 10
+"""
+
+
+def test_parse_matern_section(tmp_path):
+    write_case(tmp_path)
+    (tmp_path / 'three.ini').write_text(INTERP_INI.replace('kernel = Kernel2', 'kernel = Kernel2 Kernel3') + MATERN_SECTION)
+    it = mgpi.parse_interpolator(str(tmp_path / 'three.ini'))
+    assert [type(k).__name__ for k in it.kernel.kernels] == ['SquaredExponentialKernel', 'MaternKernel']
+    assert list(it.kernel.kernels[1].params) == [2.0, 0.1, 15.0, 10.0]
+    assert [t[0] for t in it.kernel.terms()] == [0, 2] and it.kernel.terms()[1][3] == 2.0
+
+
+@pytest.mark.gpu
+def test_all_three_example_kernels_end_to_end(tmp_path):
+    """SE + Matern(2) kernel, WhiteNoise nugget, from INI text to a conditioned process; oracle with MATERN_ZERO_LIMIT"""
+    from conftest import mean_tol, var_tol
+    from oracle import mgpi_oracle as oracle
+    g = write_case(tmp_path)
+    (tmp_path / 'three.ini').write_text(INTERP_INI.replace('kernel = Kernel2', 'kernel = Kernel2 Kernel3') + MATERN_SECTION)
+    (x, f), _ = mgpi.parse_table(str(tmp_path / 'data.ini'))
+    it = mgpi.parse_interpolator(str(tmp_path / 'three.ini'))
+    xs = g['xs'][:64]
+    mean, cov = it.condition(xs, x, f)
+    kt = [oracle.term_se(0.1, 10, 20), oracle.term_matern(2, 0.1, 15, 10)]
+    nt = [oracle.term_white(1e-4)]
+    oracle.MATERN_ZERO_LIMIT = True
+    try:
+        cond = np.linalg.cond(oracle.x2cov(kt + nt, x, x))
+        want_mean, want_cov = oracle.condition(kt, nt, xs, x, f)
+    finally:
+        oracle.MATERN_ZERO_LIMIT = False
+    assert relmax(mean, want_mean) < mean_tol(cond)
+    assert np.max(np.abs(cov - want_cov)) / 0.02 < var_tol(cond)

@@ -100,3 +100,31 @@ print("NCCL-OK")
     out = subprocess.run([sys.executable, '-c', code, str(port)], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                          capture_output=True, text=True, timeout=300)
     assert 'NCCL-OK' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+@pytest.mark.parametrize('P,Q,n,m,nb,d,lookahead', [(1, 2, 1500, 130, 256, 3, 1), (2, 1, 1100, 70, 128, 2, 1),
+                                                     (2, 2, 2100, 300, 256, 3, 1), (2, 2, 1024, 64, 128, 4, 0)])
+def test_hip_tile_backend_multi_rank_on_one_gpu(P, Q, n, m, nb, d, lookahead):
+    """P*Q ranks share GPU 0 (gloo, host-staged collectives - tests/dist_gpu_worker.py): the multi-rank tile
+    distribution with the HIP kernels, which a one-GPU box cannot otherwise run.  At most 4 ranks + this process
+    touch the card (the box allows 6)."""
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = P * Q
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dist_gpu_worker.py')
+    procs = [subprocess.Popen([sys.executable, worker] + [str(v) for v in (r, world, port, P, Q, n, m, nb, d, lookahead)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    try:
+        for pr in procs:
+            outs.append(pr.communicate(timeout=300)[0])
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    for r, (pr, out) in enumerate(zip(procs, outs)):
+        assert pr.returncode == 0 and 'RANK-%d-OK' % r in out, 'rank %d:\n%s' % (r, out[-3000:])
