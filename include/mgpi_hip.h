@@ -69,6 +69,11 @@ int  mgpi_device_count(int* count);
 int  mgpi_ctx_create(int device_id, int nb, mgpi_ctx** out);
 int  mgpi_ctx_destroy(mgpi_ctx* ctx);
 int  mgpi_ctx_sync(mgpi_ctx* ctx);                 /* wait for all queued device work */
+/* Device memory of freed matrices is kept in a per-context pool and handed to later mgpi_mat_alloc calls of a
+ * fitting size: the hyper-parameter loops of the reference (interpolators.py:382, :514) rebuild K at a fixed N
+ * thousands of times, and a hipMalloc/hipFree pair per call costs more than the factorisation below N ~ 16384.
+ * The pool is capped at a quarter of the device memory (MGPI_POOL_MB overrides, 0 disables); trim releases it. */
+int  mgpi_ctx_trim(mgpi_ctx* ctx);
 /* raw hipStream_t of the ctx (as void*), for callers that time with HIP events */
 void* mgpi_ctx_stream(mgpi_ctx* ctx);
 /* event timing on the ctx stream: tic records, toc records+synchronises and returns ms */

@@ -54,6 +54,7 @@ _SIGNATURES = {
     'mgpi_ctx_create': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
     'mgpi_ctx_destroy': (ctypes.c_int, [_vp]),
     'mgpi_ctx_sync': (ctypes.c_int, [_vp]),
+    'mgpi_ctx_trim': (ctypes.c_int, [_vp]),
     'mgpi_ctx_stream': (_vp, [_vp]),
     'mgpi_ctx_tic': (ctypes.c_int, [_vp]),
     'mgpi_ctx_toc': (ctypes.c_int, [_vp, c_double_p]),
@@ -263,6 +264,10 @@ class Context(object):
 
     def sync(self):
         check(self.lib.mgpi_ctx_sync(self.handle))
+
+    def trim(self):
+        """hand the pooled device memory of freed matrices back to the driver"""
+        check(self.lib.mgpi_ctx_trim(self.handle))
 
     def tic(self):
         check(self.lib.mgpi_ctx_tic(self.handle))

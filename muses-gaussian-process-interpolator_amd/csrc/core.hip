@@ -64,7 +64,79 @@ extern "C" int mgpi_ctx_create(int device_id, int nb, mgpi_ctx** out) {
     MGPI_HIP_TRY(hipMalloc((void**)&c->d_info, 64));
     MGPI_HIP_TRY(hipMalloc((void**)&c->d_scal, 4096 * sizeof(double)));
     MGPI_HIP_TRY(hipMemset(c->d_info, 0, 64));
+    c->pool = new mgpi_pool();
+    {
+        size_t free_b = 0, total_b = 0;
+        MGPI_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        c->pool->cap = total_b / 4;
+        if (const char* env = getenv("MGPI_POOL_MB")) c->pool->cap = (size_t)atoll(env) << 20;
+    }
     *out = c;
+    return 0;
+}
+
+// ---- device buffer pool -------------------------------------------------------------------
+// All users of a pooled buffer are ordered on ctx->stream (the look-ahead stream is joined back into it before any
+// launcher returns), and the first touch of a reused buffer is the hipMemsetAsync of mgpi_mat_alloc on that same
+// stream, so handing a block over needs no host synchronisation.
+static void pool_release(mgpi_ctx* ctx) {
+    if (!ctx->pool || ctx->pool->blocks.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& b : ctx->pool->blocks) (void)hipFree(b.ptr);
+    ctx->pool->blocks.clear();
+    ctx->pool->held = 0;
+}
+
+static int pool_alloc(mgpi_ctx* ctx, size_t bytes, double** out, size_t* got) {
+    mgpi_pool* pool = ctx->pool;
+    int best = -1;
+    for (int i = 0; i < (int)pool->blocks.size(); ++i) {
+        const size_t b = pool->blocks[i].bytes;
+        if (b >= bytes && b - bytes <= bytes / 8 && (best < 0 || b < pool->blocks[best].bytes)) best = i;
+    }
+    if (best >= 0) {
+        *out = (double*)pool->blocks[best].ptr;
+        *got = pool->blocks[best].bytes;
+        pool->held -= pool->blocks[best].bytes;
+        pool->blocks.erase(pool->blocks.begin() + best);
+        return 0;
+    }
+    hipError_t e = hipMalloc((void**)out, bytes);
+    if (e != hipSuccess && !pool->blocks.empty()) {          // give the pooled memory back and try once more
+        (void)hipGetLastError();
+        pool_release(ctx);
+        e = hipMalloc((void**)out, bytes);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        mgpi_set_error("mgpi_mat_alloc: hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        return MGPI_ERR_ALLOC;
+    }
+    *got = bytes;
+    return 0;
+}
+
+static void pool_free(mgpi_ctx* ctx, void* ptr, size_t bytes) {
+    mgpi_pool* pool = ctx->pool;
+    if (bytes > pool->cap) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ptr);
+        return;
+    }
+    while (pool->held + bytes > pool->cap && !pool->blocks.empty()) {      // evict the oldest blocks
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(pool->blocks.front().ptr);
+        pool->held -= pool->blocks.front().bytes;
+        pool->blocks.erase(pool->blocks.begin());
+    }
+    pool->blocks.push_back({ptr, bytes});
+    pool->held += bytes;
+}
+
+extern "C" int mgpi_ctx_trim(mgpi_ctx* ctx) {
+    MGPI_REQUIRE(ctx != nullptr, "mgpi_ctx_trim: null pointer");
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    pool_release(ctx);
     return 0;
 }
 
@@ -72,6 +144,8 @@ extern "C" int mgpi_ctx_destroy(mgpi_ctx* ctx) {
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    pool_release(ctx);
+    delete ctx->pool;
     if (ctx->work) (void)hipFree(ctx->work);
     if (ctx->d_diag) (void)hipFree(ctx->d_diag);
     (void)hipFree(ctx->d_info);
@@ -209,12 +283,9 @@ static int mat_alloc_impl(mgpi_ctx* ctx, int64_t rows, int64_t cols, int wide, m
     m->owns = 1;
     m->factored = 0;
     size_t bytes = (size_t)m->prows * (size_t)m->pcols * sizeof(double);
-    hipError_t e = hipMalloc((void**)&m->d, bytes);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        mgpi_set_error("mgpi_mat_alloc: hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    if (int rc = pool_alloc(ctx, bytes, &m->d, &m->alloc_bytes)) {
         delete m;
-        return MGPI_ERR_ALLOC;
+        return rc;
     }
     MGPI_HIP_TRY(hipMemsetAsync(m->d, 0, bytes, ctx->stream));
     *out = m;
@@ -233,8 +304,7 @@ extern "C" int mgpi_mat_free(mgpi_mat* m) {
     if (!m) return 0;
     if (m->owns && m->d) {
         (void)hipSetDevice(m->ctx->device);
-        (void)hipStreamSynchronize(m->ctx->stream);
-        (void)hipFree(m->d);
+        pool_free(m->ctx, m->d, m->alloc_bytes);
     }
     delete m;
     return 0;

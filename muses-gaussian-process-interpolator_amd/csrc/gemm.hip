@@ -294,6 +294,143 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(int64_t k, const doubl
                 C[(m0 + wr * WM + i * 16 + fq + 4 * r) * ldc + n0 + wc * WN + j * 16 + fr] = acc[i][j][r];
 }
 
+// ---- software-pipelined 128x128 kernel (the shipped trailing-update kernel) --------------------------------------
+// Same tile, LDS image and direct-to-LDS staging as gemm_f64_kernel<128,128,..,GLDS>, with the K loop pipelined by hand
+// around ONE barrier per stage:
+//     region 1:  ds_read half 1 of stage s -> Y          | 32 MFMAs on X (half 0 of stage s, read one region earlier)
+//     s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier            stage s+1 has landed (it was issued a whole stage ago) and
+//                                                         every wave is done reading stage s
+//     region 2:  global_load_lds stage s+2 -> buffer of s | ds_read half 0 of stage s+1 -> X | 32 MFMAs on Y
+// so the HBM/L2 loads get a full stage (64 MFMAs = 4096 cycles) to land instead of half of one, every LDS read is
+// covered by 32 MFMAs of the same wave (no reliance on the other workgroup of the CU to fill the pipe), and the
+// operand negation moves out of the loop: the accumulators start from -C, the MFMAs add A B, the epilogue stores
+// -(acc) = C - A B.  The C row pointers are recomputed in the epilogue (laundered thread id) so that they do not
+// occupy 32 VGPRs across the loop - that is what makes room for the second fragment set.
+struct gemm_yes { static constexpr bool v = true; };
+struct gemm_no  { static constexpr bool v = false; };
+
+template <bool BKM, bool LOWER>
+__global__ __launch_bounds__(256, 2) void gemm_f64_pipe_kernel(int64_t k, const double* __restrict__ A, int64_t lda,
+                                                               const double* __restrict__ B, int64_t ldb,
+                                                               double* __restrict__ C, int64_t ldc, int tiles_m,
+                                                               int tiles_n, int64_t ntiles, gemm_stair st) {
+    constexpr int BM = 128, BN = 128, WM = 64, WN = 64, FM = 4, FN = 4;
+    using GA = TileGeom<BM, false>;
+    using GB = TileGeom<BN, BKM>;
+    __shared__ __attribute__((aligned(16))) double lds[2 * (GA::doubles + GB::doubles)];
+    constexpr int STAGE = GA::doubles + GB::doubles;
+
+    int64_t bid = blockIdx.x;
+    {
+        const int64_t q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, loc = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    int ti, tj;
+    if (!LOWER && st.on) {
+        int band = 0;
+        while (band + 1 < st.nbands && st.prefix[band + 1] <= bid) ++band;
+        const int within = (int)bid - st.prefix[band];
+        const int rows = (tiles_m - band * GEMM_BAND < GEMM_BAND) ? (tiles_m - band * GEMM_BAND) : GEMM_BAND;
+        tj = within / rows;
+        ti = band * GEMM_BAND + within - tj * rows;
+        const int I = st.p + st.P * (st.bi0 + ti / st.tpb), J = st.q + st.Q * (st.bj0 + tj / st.tpb);
+        if (I < J || (I == J && (ti % st.tpb) < (tj % st.tpb))) return;
+    } else {
+        tile_decode<LOWER>(bid, tiles_m, tiles_n, ti, tj);
+    }
+    const int64_t m0 = (int64_t)ti * BM, n0 = (int64_t)tj * BN;
+    const int tid = threadIdx.x;
+
+    tile_glds<false>(A, lda, m0, 0, tid, lds);
+    tile_glds<BKM>(B, ldb, n0, 0, tid, lds + GA::doubles);
+
+    double4_t acc[FM][FN];
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const double* c0 = C + (m0 + (wave >> 1) * WM + (lane >> 4)) * ldc + n0 + (wave & 1) * WN + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = -c0[(i * 16 + 4 * r) * ldc + j * 16];
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int64_t nk = k / GEMM_BK;
+    __syncthreads();                                              // stage 0 landed
+    if (nk > 1) {
+        tile_glds<false>(A, lda, m0, GEMM_BK, tid, lds + STAGE);
+        tile_glds<BKM>(B, ldb, n0, GEMM_BK, tid, lds + STAGE + GA::doubles);
+    }
+
+    double xa[FM][2], xb[FN][2], ya[FM][2], yb[FN][2];
+    auto read_half = [&](const double* __restrict__ la, const double* __restrict__ lb, int h, double (&fa)[FM][2],
+                         double (&fb)[FN][2]) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) frag_pair<BM, false>(la, wr * WM + i * 16 + fr, h, fq, fa[i]);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) frag_pair<BN, BKM>(lb, wc * WN + j * 16 + fr, h, fq, fb[j]);
+    };
+    // MFMAs lo..hi-1 of a half stage (32 in all: 2 k-steps x 4 x 4 accumulator tiles)
+    auto mfma_range = [&](const double (&fa)[FM][2], const double (&fb)[FN][2], int lo, int hi) {
+#pragma unroll
+        for (int t = 0; t < 2 * FM * FN; ++t) {
+            const int s2 = t / (FM * FN), i = (t / FN) % FM, j = t % FN;
+            if (t >= lo && t < hi)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i][s2], fb[j][s2], acc[i][j], 0, 0, 0);
+        }
+    };
+    auto body = [&](int64_t kt, auto refill, auto more) {
+        const int cur = (int)(kt & 1);
+        const double* la = lds + cur * STAGE;
+        const double* lb = la + GA::doubles;
+        // The sched_barriers pin "first MFMA, then the loads, then the MFMAs that cover them".  Left alone the scheduler
+        // sinks the reads below the MFMAs (one fragment set, fewer registers) and their latency is exposed at the
+        // barrier; and a read issued BEFORE the first MFMA drags that MFMA's s_waitcnt down to lgkmcnt(0), i.e. the
+        // wave would wait for the reads it has just issued instead of only for the fragments it needs.
+        mfma_range(xa, xb, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_half(la, lb, 1, ya, yb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_range(xa, xb, 1, 32);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_range(ya, yb, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (decltype(refill)::v) {
+            tile_glds<false>(A, lda, m0, (kt + 2) * GEMM_BK, tid, lds + cur * STAGE);
+            tile_glds<BKM>(B, ldb, n0, (kt + 2) * GEMM_BK, tid, lds + cur * STAGE + GA::doubles);
+        }
+        if constexpr (decltype(more)::v) read_half(lds + (cur ^ 1) * STAGE, lds + (cur ^ 1) * STAGE + GA::doubles, 0, xa, xb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_range(ya, yb, 1, 32);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    read_half(lds, lds + GA::doubles, 0, xa, xb);
+    int64_t kt = 0;
+    for (; kt + 2 < nk; ++kt) body(kt, gemm_yes(), gemm_yes());
+    if (nk >= 2) body(nk - 2, gemm_no(), gemm_yes());
+    body(nk - 1, gemm_no(), gemm_no());
+
+    // epilogue: acc = -(C - A B).  The addresses are rebuilt from a laundered thread id (see the header comment).
+    int tid2 = tid;
+    asm volatile("" : "+v"(tid2));
+    {
+        const int lane2 = tid2 & 63, wave2 = tid2 >> 6;
+        double* c0 = C + (m0 + (wave2 >> 1) * WM + (lane2 >> 4)) * ldc + n0 + (wave2 & 1) * WN + (lane2 & 15);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c0[(i * 16 + 4 * r) * ldc + j * 16] = -acc[i][j][r];
+    }
+}
+
 // ---- ping-pong variant: two 4-wave groups per 512-thread workgroup, one workgroup per CU ----------------------
 // Each group owns one 128x128 tile (its own LDS double buffer, its own accumulators) and runs the loop above,
 // but the groups are staggered by one barrier: every K-stage has two workgroup barriers, and between two
@@ -433,6 +570,25 @@ static int launch_one(mgpi_ctx* ctx, int64_t m, int64_t n, int64_t k, const doub
     return 0;
 }
 
+template <bool BKM, bool LOWER>
+static int launch_pipe(mgpi_ctx* ctx, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, const double* B,
+                       int64_t ldb, double* C, int64_t ldc, gemm_stair st = no_stair()) {
+    const int64_t tm = m / 128, tn = n / 128;
+    const int64_t ntiles = LOWER ? tm * (tm + 1) / 2 : (st.on ? (int64_t)st.prefix[st.nbands] : tm * tn);
+    MGPI_REQUIRE(ntiles > 0 && ntiles < (int64_t)2147483647, "gemm: tile count %lld out of range", (long long)ntiles);
+    hipLaunchKernelGGL((gemm_f64_pipe_kernel<BKM, LOWER>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, k, A, lda, B, ldb,
+                       C, ldc, (int)tm, (int)tn, ntiles, st);
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// hand-pipelined 128x128 kernel (default); MGPI_GEMM_PIPE=0 falls back to gemm_f64_kernel<128,128,...> (developer
+// switch, both forms are tested)
+static bool use_pipe() {
+    static const char* env = getenv("MGPI_GEMM_PIPE");
+    return env ? atoi(env) != 0 : true;
+}
+
 // the ping-pong kernel is a MEASURED VARIANT, off by default: strict alternation of two 4-wave groups reached
 // 53.5 TFLOP/s at n=32256 against 61.3 for two independent workgroups per CU (whose prologue/epilogue overlap
 // the other workgroup's main loop).  MGPI_GEMM_PP=1 selects it (developer switch, tested).
@@ -456,11 +612,13 @@ static int launch_shape(mgpi_ctx* ctx, int lower_only, int64_t m, int64_t n, int
         MGPI_REQUIRE(m == n && m % 128 == 0, "gemm(lower): needs m == n, multiple of 128 (got %lld x %lld)", (long long)m,
                      (long long)n);
         if (use_pp(m / 128 * (m / 128 + 1) / 2)) return launch_pp<AK, BKM, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
+        if constexpr (!AK) if (use_pipe()) return launch_pipe<BKM, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
         if (use_glds()) return launch_one<128, 128, AK, BKM, true, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
         return launch_one<128, 128, AK, BKM, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
     }
     if (m % 128 == 0 && n % 128 == 0) {
         if (use_pp((m / 128) * (n / 128))) return launch_pp<AK, BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
+        if constexpr (!AK) if (use_pipe()) return launch_pipe<BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
         if (use_glds()) return launch_one<128, 128, AK, BKM, false, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
         return launch_one<128, 128, AK, BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
     }
@@ -543,7 +701,8 @@ extern "C" int mgpi_gemm_nt_stair_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mg
     st.prefix[st.nbands] = (int)total;
     if (total == 0) return 0;
     mgpi_prof_begin(ctx, 0);
-    int rc = use_glds() ? launch_one<128, 128, false, false, false, true>(ctx, m, n, k, A->d, A->ld, B->d, B->ld, C->d, C->ld, st)
+    int rc = use_pipe() ? launch_pipe<false, false>(ctx, m, n, k, A->d, A->ld, B->d, B->ld, C->d, C->ld, st)
+           : use_glds() ? launch_one<128, 128, false, false, false, true>(ctx, m, n, k, A->d, A->ld, B->d, B->ld, C->d, C->ld, st)
                         : launch_one<128, 128, false, false, false, false>(ctx, m, n, k, A->d, A->ld, B->d, B->ld, C->d, C->ld, st);
     mgpi_prof_end(ctx, 0);
     return rc;

@@ -18,6 +18,8 @@ struct mgpi_prof_slot {
     int64_t launches;
 };
 
+struct mgpi_pool;
+
 struct mgpi_ctx {
     int device;
     int nb;                       // outer Cholesky block
@@ -36,6 +38,7 @@ struct mgpi_ctx {
     int64_t diag_len;
     double* work;                 // device workspace, grown on demand
     size_t work_bytes;
+    mgpi_pool* pool;              // freed matrix buffers awaiting reuse (core.hip)
 };
 
 struct mgpi_mat {
@@ -46,6 +49,13 @@ struct mgpi_mat {
     double* d;                    // device pointer to element (0,0)
     int owns;
     int factored;                 // set by potrf
+    size_t alloc_bytes;           // owners: size of the device block (>= prows*pcols*8 when it came from the pool)
+};
+
+struct mgpi_pool_block { void* ptr; size_t bytes; };
+struct mgpi_pool {
+    std::vector<mgpi_pool_block> blocks;   // oldest first
+    size_t held = 0, cap = 0;
 };
 
 // ---- error plumbing -------------------------------------------------------------------
