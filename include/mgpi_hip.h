@@ -176,6 +176,25 @@ int  mgpi_trsv_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* v, int trans);
 /* y -= A x (trans=0) or y -= A^T x (trans=1); x, y vectors (ld == 1) */
 int  mgpi_gemv_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* x, mgpi_mat* y, int trans);
 
+/* ---- NearestNeighborInterpolator (mgpi/interpolators.py:612-871) ----------------------
+ * Host pointers in and out; the reference's own neighbour sets are host-side index lists too (:744, :833). */
+#define MGPI_NN_MAX_NEIGHBORS 62
+/* _2neighbors (:654-744).  source_x (n x d) must already be sorted by rank (_2sorted, :645-652; source_rank ascending).
+ * target_x == NULL: reference-set mode, sample i against the samples in front of it (m is ignored, n targets).
+ * rank_is_sum: ranks are sum(x) (order_by_index None) rather than one coordinate; it selects the lower bound on the
+ * distance that lets the scan stop early (the scan is O(N sqrt(k N)) in 2-D instead of the reference's O(N^2)).
+ * out_index: (m x k) closest first, -1 padded; out_count: (m).  Euclidean distance, samples ranked above the target or
+ * coinciding with it are skipped, as in the reference; equal distances go to the lower index. */
+int  mgpi_nn_neighbors(mgpi_ctx* ctx, const double* source_x, const double* source_rank, int64_t n, int d,
+                       const double* target_x, const double* target_rank, int64_t m, int k, int rank_is_sum,
+                       int32_t* out_index, int32_t* out_count);
+/* _2diag / _sample2diag (:751-792): mean and variance of every target given its neighbour set; terms = the kernel's
+ * nkernel summands followed by the nugget's.  A point without neighbours gets (0, k(x,x) + nugget(x,x)); a neighbour
+ * matrix that is not positive definite gives NaN for that point. */
+int  mgpi_nn_condition(mgpi_ctx* ctx, const double* target_x, int64_t m, const double* source_x, const double* source_f,
+                       int64_t n, int d, const int32_t* index, const int32_t* count, int k, const mgpi_kernel_desc* terms,
+                       int nterms, int nkernel, double* out_mean, double* out_diag);
+
 /* measured throughput probes used by bench.py's roofline leg (not part of the hot path) */
 int  mgpi_probe_mfma_f64(mgpi_ctx* ctx, int iters, double* tflops);
 int  mgpi_probe_hbm(mgpi_ctx* ctx, int64_t bytes, int iters, double* read_gbs, double* write_gbs);

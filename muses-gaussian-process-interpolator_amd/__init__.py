@@ -9,6 +9,7 @@ reference's (mgpi/__init__.py:7-10).
 from .utils import *            # noqa: F401,F403
 from .kernel_objects import *   # noqa: F401,F403
 from .gp import *               # noqa: F401,F403
+from .nngp import *             # noqa: F401,F403
 from .config import *           # noqa: F401,F403
 from . import _lib              # noqa: F401
 from ._lib import Context, DeviceMatrix, MgpiError, NotPositiveDefinite, default_context, set_default_context  # noqa: F401

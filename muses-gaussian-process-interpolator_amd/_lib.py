@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, 'libmgpi_hip.so')
 
 MAX_D = 16
 MAX_TERMS = 8
+NN_MAX_NEIGHBORS = 62
 TERM_SE = 0
 TERM_WHITE = 1
 TERM_MATERN = 2
@@ -72,6 +73,9 @@ _SIGNATURES = {
     'mgpi_mat_unscale': (ctypes.c_int, [_vp, _vp, _vp]),
     'mgpi_mat_view': (ctypes.c_int, [_vp, c_int64, c_int64, c_int64, c_int64, ctypes.POINTER(_vp)]),
     'mgpi_cov_paired': (ctypes.c_int, [_vp, _vp, _vp, c_int64, ctypes.c_int, ctypes.POINTER(KernelDesc), ctypes.c_int, _vp]),
+    'mgpi_nn_neighbors': (ctypes.c_int, [_vp, _vp, _vp, c_int64, ctypes.c_int, _vp, _vp, c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp]),
+    'mgpi_nn_condition': (ctypes.c_int, [_vp, _vp, c_int64, _vp, _vp, c_int64, ctypes.c_int, _vp, _vp, ctypes.c_int,
+                                         ctypes.POINTER(KernelDesc), ctypes.c_int, ctypes.c_int, _vp, _vp]),
     'mgpi_cov_matrix': (ctypes.c_int, [_vp, _vp, c_int64, _vp, c_int64, ctypes.c_int, ctypes.POINTER(KernelDesc), ctypes.c_int, _vp]),
     'mgpi_cov_matrix_dev': (ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(KernelDesc), ctypes.c_int, ctypes.c_int, _vp]),
     'mgpi_potrf_dev': (ctypes.c_int, [_vp, _vp, c_double_p]),

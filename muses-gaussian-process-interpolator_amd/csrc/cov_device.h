@@ -84,9 +84,10 @@ __device__ __forceinline__ double mgpi_matern_shape(double x, int nl, double mu,
 }
 
 // D > 0: compile-time dimensionality (registers, fully unrolled); D == 0: runtime t.d (<= MGPI_MAX_D)
+// summands [lo, hi) of the kernel: the NNGP path needs kernel-only and nugget-only sums next to the full one
 template <int D>
-__device__ __forceinline__ double mgpi_cov_entry(const mgpi_terms_dev& t, const double* __restrict__ a,
-                                                 const double* __restrict__ b) {
+__device__ __forceinline__ double mgpi_cov_entry_range(const mgpi_terms_dev& t, const double* __restrict__ a,
+                                                       const double* __restrict__ b, int lo, int hi) {
     const int nd = (D > 0) ? D : t.d;
     // coordinate differences are shared by all terms; (x1 == x2) <=> (x1 - x2 == 0) for finite fp64
     double diff2[(D > 0) ? D : MGPI_MAX_D];
@@ -100,7 +101,7 @@ __device__ __forceinline__ double mgpi_cov_entry(const mgpi_terms_dev& t, const 
         }
     }
     double val = 0.0;
-    for (int s = 0; s < t.nterms; ++s) {
+    for (int s = lo; s < hi; ++s) {
         if (t.type[s] == MGPI_TERM_SE) {
             double r = 0.0;
 #pragma unroll
@@ -123,4 +124,10 @@ __device__ __forceinline__ double mgpi_cov_entry(const mgpi_terms_dev& t, const 
         }
     }
     return val;
+}
+
+template <int D>
+__device__ __forceinline__ double mgpi_cov_entry(const mgpi_terms_dev& t, const double* __restrict__ a,
+                                                 const double* __restrict__ b) {
+    return mgpi_cov_entry_range<D>(t, a, b, 0, t.nterms);
 }

@@ -189,3 +189,91 @@ def diag_variance_cholesky(kernel, L, target_x, source_x, chunk=1024):
         v = solve_triangular(L, ks.T, lower=True)
         out[lo:lo + chunk] = paired_cov(kterms, t, t) - np.sum(v * v, axis=0)
     return out
+
+#-------------------------------------------------
+# NearestNeighborInterpolator (NNGP, Datta et al. 2016): mgpi/interpolators.py:612-871
+# restated without the progress printing; every selection rule and its quirks are kept:
+#   * samples are ordered by sum(x) (or one coordinate), and a point's neighbours are the num_neighbors closest
+#     samples - plain Euclidean distance, NOT scaled by the kernel lengths - among those ranked at or below it;
+#   * samples that coincide exactly with the point are never its neighbours, so an NNGP prediction AT a training
+#     point does not use that point;
+#   * numpy's default argsort decides ties in distance (unspecified order).  ``stable=True`` is the product's rule
+#     (ties go to the lower index in the sorted reference set); the two agree whenever distances are distinct.
+
+
+def nn_rank(x, order_by_index=None):
+    """:633-640"""
+    return np.sum(x) if order_by_index is None else x[order_by_index]
+
+
+def nn_ranks(x, order_by_index=None):
+    """:642-643"""
+    return np.array([nn_rank(row, order_by_index) for row in x])
+
+
+def nn_sorted(source_x, source_f=None, order_by_index=None):
+    """:645-652"""
+    order = np.argsort(nn_ranks(source_x, order_by_index))
+    return source_x[order], (source_f[order] if source_f is not None else None)
+
+
+def nn_neighbors(source_x, target_x=None, num_neighbors=10, order_by_index=None, stable=False):
+    """list of index arrays into the SORTED reference set, one per target, closest first   (:654-744)"""
+    source_x = np.asarray(source_x, dtype=float)
+    within = target_x is None
+    targets = source_x if within else np.asarray(target_x, dtype=float)
+    ranks = nn_ranks(source_x, order_by_index)
+    every = np.arange(len(source_x))
+    visible = 0 if within else len(source_x)        # :663-670 samples [0, visible) may be neighbours
+    out = []
+    for x in targets:
+        ok = np.zeros(len(source_x), dtype=bool)
+        ok[:visible] = ranks[:visible] <= nn_rank(x, order_by_index)          # :695-696
+        ok[every[ok][np.all(source_x[ok] == x, axis=1)]] = False               # :706-718 exact matches dropped
+        if ok.any():
+            dist = np.sum((source_x[ok] - x)**2, axis=1)                       # :725
+            order = np.argsort(dist, kind='stable') if stable else np.argsort(dist)
+            out.append(every[ok][order][:num_neighbors])                       # :730
+        else:
+            out.append([])                                                     # :741
+        visible += 1                                                           # :744
+    return out
+
+
+def nn_sample2diag(kernel, nugget, x, ref_x, ref_f):
+    """(mean, variance) of one point given its neighbour set   (:751-776)"""
+    if len(ref_x) == 0:
+        diag = paired_cov(list(kernel), x, x)[0]
+        if nugget:
+            diag += paired_cov(list(nugget), x, x)[0]
+        return 0.0, diag
+    m, c = condition(kernel, nugget, x, ref_x, ref_f)
+    mean, diag = m[0], c[0, 0]
+    assert mean == mean, 'mean is nan'
+    assert diag == diag, 'diag is nan'
+    assert diag > 0, 'marginal variance is negative!'
+    return mean, diag
+
+
+def nn_2diag(kernel, nugget, target_x, source_x, source_f, neighbors):
+    """(2, M): means and variances   (:780-792)"""
+    source_x = np.asarray(source_x, dtype=float)
+    return np.transpose([nn_sample2diag(kernel, nugget, target_x[[i]], source_x[np.asarray(neighbors[i], dtype=int)],
+                                        source_f[np.asarray(neighbors[i], dtype=int)]) for i in range(len(target_x))])
+
+
+def nn_loglikelihood(kernel, nugget, source_x, source_f, num_neighbors=10, order_by_index=None, neighbors=None, stable=False):
+    """sum of independent 1-D Gaussians   (:833-846)"""
+    if neighbors is None:
+        source_x, source_f = nn_sorted(source_x, source_f, order_by_index)
+        neighbors = nn_neighbors(source_x, None, num_neighbors, order_by_index, stable)
+    mean, diag = nn_2diag(kernel, nugget, source_x, source_x, source_f, neighbors)
+    return -0.5 * np.sum((mean - source_f)**2 / diag) - 0.5 * np.sum(np.log(diag)) - 0.5 * len(source_x) * np.log(2 * np.pi)
+
+
+def nn_condition(kernel, nugget, target_x, source_x, source_f, num_neighbors=10, order_by_index=None, stable=False):
+    """(mean, diagonal covariance matrix)   (:850-884)"""
+    source_x, source_f = nn_sorted(source_x, source_f, order_by_index)
+    neighbors = nn_neighbors(source_x, target_x, num_neighbors, order_by_index, stable)
+    mean, diag = nn_2diag(kernel, nugget, np.asarray(target_x, dtype=float), source_x, source_f, neighbors)
+    return mean, np.diag(diag)

@@ -22,7 +22,17 @@ def _all_golden():
 
 def golden_names():
     """the full-path fixtures (kernel matrices + compress/predict/condition/loglikelihood outputs)"""
-    return [n for n in _all_golden() if not n.startswith('matern_')]
+    return [n for n in _all_golden() if not n.startswith(('matern_', 'nngp_'))]
+
+
+def nngp_names():
+    """NearestNeighborInterpolator fixtures (sorted set, neighbour lists, per-point means/variances, loglikelihood)"""
+    return [n for n in _all_golden() if n.startswith('nngp_')]
+
+
+def neighbor_lists(padded):
+    """-1 padded (M, k) index array -> list of index arrays, the reference's return type"""
+    return [row[row >= 0] for row in np.asarray(padded)]
 
 
 def matern_names():

@@ -113,6 +113,110 @@ def run_matern(name, x, xs, order, sigma, lengths, extra=()):
     print('%-28s N=%-5d M=%-5d D=%d order=%g  NaN entries in K: %d' % (name, len(x), len(xs), x.shape[1], order, np.isnan(K).sum()))
 
 
+def pad_neighbors(neighbors, k):
+    idx = -np.ones((len(neighbors), k), dtype=np.int32)
+    for i, nb in enumerate(neighbors):
+        idx[i, :len(nb)] = nb
+    return idx
+
+
+def nngp_loglike_longdouble(kernel, nugget, sx, sf, neighbors):
+    """the NNGP loglikelihood (interpolators.py:833-846) on the reference's own neighbour sets, with every per-point
+    conditional worked out by a Cholesky in 80-bit extended precision.  NOT a reference output: a yardstick for it.
+    The reference's LU-inverse loses ~cond * eps in each conditional variance and the loglikelihood divides by those
+    variances, so its own value carries an error of 1e-9..1e-8 relative (measured against this number), four orders
+    above what a fp64 Cholesky delivers; the parity test needs to know which of the two it is looking at."""
+    LD = np.longdouble
+
+    def cov(terms, a, b):
+        tot = LD(0)
+        for t in terms:
+            if t[0] == 'se':
+                tot += LD(t[1])**2 * np.exp(-sum(((LD(u) - LD(v)) / LD(l))**2 for u, v, l in zip(a, b, t[2])))
+            else:
+                tot += LD(t[1])**2 * (1 if all(u == v for u, v in zip(a, b)) else 0)
+        return tot
+
+    both = list(kernel) + list(nugget)
+    ll = LD(0)
+    for i in range(len(sx)):
+        idx = neighbors[i]
+        c = len(idx)
+        if c == 0:
+            mean, diag = LD(0), cov(both, sx[i], sx[i])
+        else:
+            K = np.array([[cov(both, sx[a], sx[b]) for b in idx] for a in idx], dtype=LD)
+            ks = np.array([cov(kernel, sx[i], sx[b]) for b in idx], dtype=LD)
+            L = np.zeros((c, c), dtype=LD)
+            v, w = np.zeros(c, dtype=LD), np.zeros(c, dtype=LD)
+            for j in range(c):
+                L[j, j] = np.sqrt(K[j, j] - np.sum(L[j, :j]**2))
+                for r in range(j + 1, c):
+                    L[r, j] = (K[r, j] - np.sum(L[r, :j] * L[j, :j])) / L[j, j]
+                v[j] = (ks[j] - np.sum(L[j, :j] * v[:j])) / L[j, j]
+                w[j] = (LD(sf[idx[j]]) - np.sum(L[j, :j] * w[:j])) / L[j, j]
+            mean, diag = np.sum(v * w), cov(kernel, sx[i], sx[i]) - np.sum(v * v)
+        ll += -(mean - LD(sf[i]))**2 / diag / 2 - np.log(diag) / 2
+    return float(ll - LD(len(sx)) * np.log(2 * LD(np.pi)) / 2)
+
+
+def run_nngp(name, x, f, xs, kernel, nugget, k, obi, tie_free=True):
+    """NearestNeighborInterpolator (interpolators.py:612-871): sorted training set, neighbour lists (reference-set
+    mode and target mode, -1 padded), per-point means/variances, loglikelihood, condition"""
+    x = np.ascontiguousarray(x, dtype=float)
+    xs = np.ascontiguousarray(xs, dtype=float)
+    f = np.ascontiguousarray(f, dtype=float)
+    nn = mgpi.NearestNeighborInterpolator(build(kernel), nugget=build(nugget), num_neighbors=k, order_by_index=obi)
+    sx, sf = nn._2sorted(x, source_f=f)
+    nb_self = nn._2neighbors(sx)
+    nb_tar = nn._2neighbors(sx, target_x=xs)
+    self_mean, self_diag = nn._2diag(sx, sx, sf, nb_self)
+    mean, cov = nn.condition(xs, x, f)
+    out = dict(x=x, f=f, xs=xs, k=np.array(k), obi=np.array(-1 if obi is None else obi), tie_free=np.array(tie_free),
+               sorted_x=sx, sorted_f=sf, nb_self=pad_neighbors(nb_self, k), nb_target=pad_neighbors(nb_tar, k),
+               self_mean=self_mean, self_diag=self_diag, cond_mean=mean, cond_diag=np.diag(cov).copy(),
+               loglike=np.array(nn.loglikelihood(x, f)),
+               loglike_longdouble=np.array(nngp_loglike_longdouble(kernel, nugget, sx, sf, nb_self)))
+    out.update(encode(kernel, x.shape[1], 'kernel'))
+    out.update(encode(nugget, x.shape[1], 'nugget'))
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('%-28s N=%-5d M=%-5d D=%d k=%d obi=%s empty target sets: %d   loglike %.9f (80-bit Cholesky: %.9f)' %
+          (name, len(x), len(xs), x.shape[1], k, obi, sum(len(n) == 0 for n in nb_tar), out['loglike'], out['loglike_longdouble']))
+
+
+def nngp_cases():
+    rng = np.random.default_rng(31)
+    x = rng.random((400, 2))
+    f = np.sin(4 * x[:, 0]) * np.cos(3 * x[:, 1]) + 0.3 * x[:, 1]
+    xs = rng.random((80, 2))
+    xs[0] = x[17]                       # coincides with a training point: that point is excluded from its neighbours
+    xs[1] = [-1.0, -1.0]                # ranked below every training point: no neighbours at all
+    xs[2] = [2.0, 2.0]                  # ranked above everything
+    se, wn = ('se', 0.8, (0.25, 0.2)), ('white', 0.8e-3)
+    run_nngp('nngp_rand2d_k10', x, f, xs, [se], [wn], 10, None)
+    run_nngp('nngp_rand2d_obi0_k7', x, f, xs, [se, wn], [], 7, 0)
+    run_nngp('nngp_rand2d_obi1_k14', x, f, xs, [se], [wn], 14, 1)
+    run_nngp('nngp_rand2d_k15', x, f, xs, [se], [wn], 15, None)
+    run_nngp('nngp_rand2d_k30', x, f, xs, [se], [('white', 3e-3)], 30, None)
+    run_nngp('nngp_rand2d_k40', x, f, xs, [se], [('white', 3e-3)], 40, None)
+    x3 = rng.random((300, 3))
+    f3 = np.sin(3 * x3[:, 0]) + x3[:, 1] * x3[:, 2]
+    run_nngp('nngp_rand3d_k5', x3, f3, rng.random((40, 3)), [('se', 1.0, (0.4, 0.4, 0.4))], [('white', 1e-2)], 5, None)
+    run_nngp('nngp_fewer_than_k', x[:6], f[:6], xs[:9], [se], [wn], 10, None)
+    x9 = rng.random((150, 9))           # D >= 8: numpy's pairwise summation order in the rank and the distance
+    run_nngp('nngp_rand9d_k6', x9, np.sin(x9.sum(axis=1)), rng.random((20, 9)), [('se', 1.0, (1.5,) * 9)], [('white', 1e-2)], 6, None)
+    # regular grid, checkerboard-thinned like test/uiuc/uiuc-test-nngp-timing:117-150 - distances tie everywhere
+    g = np.linspace(0.0, 1.0, 16)
+    G0, G1 = np.meshgrid(g, g, indexing='ij')
+    keep = ~((np.arange(16)[:, None] % 2 == 1) & (np.arange(16)[None, :] % 2 == 1))
+    xg = np.transpose([G0[keep], G1[keep]])
+    fg = np.tanh(3 * (xg[:, 1] - 0.5)) + 0.1 * np.sin(5 * xg[:, 0])
+    sig = 1.5 * np.std(fg)
+    ell = (2 * (g[1] - g[0]),) * 2
+    run_nngp('nngp_grid2d_ties_k10', xg, fg, np.transpose([G0[~keep], G1[~keep]]), [('se', sig, ell), ('white', sig / 1000)], [], 10, 0,
+             tie_free=False)
+
+
 def smooth(x):
     """a smooth scalar field on [0,1]^D-ish inputs"""
     x = np.asarray(x, dtype=float)
@@ -153,6 +257,8 @@ def main():
     # no white noise at all, well separated points (K well conditioned on its own)
     x = rng.random((30, 2)) * 4.0
     run('toy_nonugget', x, smooth(x), rng.random((6, 2)) * 4.0, [('se', 1.0, (0.5, 0.5))], [])
+
+    nngp_cases()
 
     # Matern (kernels.py:135-162): etc/example-interpolator.ini's Kernel3 (order 2, sigma 0.1, lengths 15 10) on a
     # (muB, T)-like scatter, half-integer and non-integer orders, tiny and huge separations

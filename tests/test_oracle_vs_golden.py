@@ -7,7 +7,7 @@ K entries bit-exact; solves within a few ulp * cond(K)."""
 import numpy as np
 import pytest
 
-from conftest import golden_names, load_golden, matern_names, matern_terms, mean_tol, oracle_terms, prior_var, relmax, var_tol
+from conftest import golden_names, load_golden, matern_names, matern_terms, neighbor_lists, nngp_names, mean_tol, oracle_terms, prior_var, relmax, var_tol
 from oracle import mgpi_oracle as oracle
 
 NAMES = golden_names()
@@ -113,3 +113,32 @@ def test_oracle_matern_matches_reference(name):
     assert np.array_equal(K1[off], g['K'][off])
     extra = sum(float(s)**2 for s in g['extra_sigmas'])     # SE and white summands are sigma**2 on the diagonal
     np.testing.assert_allclose(np.diag(K1), float(g['sigma'])**2 + extra, rtol=1e-15)
+
+
+@pytest.mark.parametrize('name', nngp_names())
+def test_oracle_nngp_matches_reference(name):
+    """interpolators.py:612-871: ordering, neighbour selection (both modes), per-point conditioning, loglikelihood.
+    Same numpy calls on the same data -> index lists identical, floating-point results to LU reproducibility."""
+    g = load_golden(name)
+    kernel, nugget = oracle_terms(g, 'kernel'), oracle_terms(g, 'nugget')
+    k, obi = int(g['k']), (None if int(g['obi']) < 0 else int(g['obi']))
+    sx, sf = oracle.nn_sorted(g['x'], g['f'], obi)
+    assert np.array_equal(sx, g['sorted_x']) and np.array_equal(sf, g['sorted_f'])
+    nb_self = oracle.nn_neighbors(sx, None, k, obi)
+    nb_tar = oracle.nn_neighbors(sx, g['xs'], k, obi)
+    for got, want in [(nb_self, neighbor_lists(g['nb_self'])), (nb_tar, neighbor_lists(g['nb_target']))]:
+        assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+    if bool(g['tie_free']):      # the product's tie rule picks the same sets when no two distances are equal
+        stable = oracle.nn_neighbors(sx, g['xs'], k, obi, stable=True)
+        assert all(np.array_equal(a, b) for a, b in zip(stable, nb_tar))
+    mean, diag = oracle.nn_2diag(kernel, nugget, sx, sx, sf, nb_self)
+    np.testing.assert_allclose(mean, g['self_mean'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(diag, g['self_diag'], rtol=1e-9, atol=1e-15)
+    mean, cov = oracle.nn_condition(kernel, nugget, g['xs'], g['x'], g['f'], k, obi)
+    np.testing.assert_allclose(mean, g['cond_mean'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.diag(cov), g['cond_diag'], rtol=1e-9, atol=1e-15)
+    assert np.count_nonzero(cov - np.diag(np.diag(cov))) == 0
+    ll = oracle.nn_loglikelihood(kernel, nugget, g['x'], g['f'], k, obi)
+    assert abs(ll - float(g['loglike'])) <= 1e-10 * abs(float(g['loglike']))
+    # the reference's (and so the oracle's) LU-inverse value against the 80-bit Cholesky yardstick stored with it
+    assert abs(ll - float(g['loglike_longdouble'])) <= 1e-7 * abs(ll)
