@@ -40,7 +40,7 @@ def main():
             nn.loglikelihood(sx, sf, neighbors=nb)
             pre.append(time.perf_counter() - t0)
         pairs = len(x) * (len(x) - 1) / 2
-        print('N=%8d  loglikelihood %.5f s | presorted %.5f s | neighbour search %.5f s (= %.2f Gpair/s of the reference's N(N-1)/2 scan)   logL %.6e   published %s'
+        print('N=%8d  loglikelihood %.5f s | presorted %.5f s | neighbour search %.5f s (= %.2f Gpair/s of the N(N-1)/2 scan of the reference)   logL %.6e   published %s'
               % (len(x), min(full), min(pre), min(search), pairs / min(search) / 1e9, ll,
                  ('%.4g s | %.4g s' % pub) if pub else 'not run'), flush=True)
 
