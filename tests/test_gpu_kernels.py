@@ -188,3 +188,17 @@ def test_gemm_staircase_matches_block_cyclic_definition(ctx, P, p, Q, q, bi0, bj
     live = gr[:, None] >= gc[None, :]
     assert np.array_equal(got[live], full[live])
     assert np.array_equal(got[~live], C[~live])
+
+
+@pytest.mark.parametrize('env', [{'MGPI_GEMM_PIPE': '0'}, {'MGPI_GEMM_PIPE': '0', 'MGPI_GEMM_GLDS': '0'}, {'MGPI_GEMM_PP': '1'},
+                                 {'MGPI_NO_LOOKAHEAD': '1'}, {'MGPI_POOL_MB': '0'}, {'MGPI_HIP_RUNTIME': 'system'}, {}],
+                         ids=lambda e: ','.join('%s=%s' % kv for kv in e.items()) or 'defaults')
+def test_developer_switch_variants(env):
+    """every kernel variant kept behind an environment switch (DESIGN.md section c) computes the same results:
+    the plain and register-staged 128x128 gemm, the ping-pong gemm, no look-ahead, no buffer pool, /opt/rocm's runtime"""
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'variant_worker.py')
+    out = subprocess.run([sys.executable, worker], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'VARIANT-OK' in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]

@@ -1,0 +1,55 @@
+"""One process per developer switch (tests/test_gpu_kernels.py::test_developer_switch_variants): the environment
+variable is read once when the library first launches a gemm, so every variant needs a fresh process.  Checks the
+128x128 gemm forms with integer-valued operands (exact in fp64), the NN form, and a factorisation + solve."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import mgpi_amd as mgpi
+from mgpi_amd import _lib
+
+ctx = mgpi.Context(device=0)
+lib, h = ctx.lib, ctx.handle
+rng = np.random.default_rng(0)
+
+
+def dev(a):
+    return _lib.DeviceMatrix.from_host(ctx, a, wide=True)
+
+
+for (m, n, k) in [(256, 384, 512), (640, 640, 48), (128, 128, 16)]:
+    A = rng.integers(-3, 4, size=(m, k)).astype(float)
+    B = rng.integers(-3, 4, size=(n, k)).astype(float)
+    C0 = rng.integers(-5, 6, size=(m, n)).astype(float)
+    dA, dB, dC = dev(A), dev(B), dev(C0)
+    _lib.check(lib.mgpi_gemm_nt_dev(h, dA.handle, dB.handle, dC.handle, 0))
+    assert np.array_equal(dC.to_host(), C0 - A @ B.T), ('NT', m, n, k)
+    dBn, dC2 = dev(np.ascontiguousarray(B.T)), dev(C0)
+    _lib.check(lib.mgpi_gemm_nn_dev(h, dA.handle, dBn.handle, dC2.handle))
+    assert np.array_equal(dC2.to_host(), C0 - A @ B.T), ('NN', m, n, k)
+    if m == n:
+        dC3 = dev(C0)
+        _lib.check(lib.mgpi_gemm_nt_dev(h, dA.handle, dA.handle, dC3.handle, 1))
+        got, want = dC3.to_host(), C0 - A @ A.T
+        for ti in range(m // 128):
+            for tj in range(n // 128):
+                blk = (slice(128 * ti, 128 * ti + 128), slice(128 * tj, 128 * tj + 128))
+                assert np.array_equal(got[blk], want[blk] if tj <= ti else C0[blk]), ('lower', ti, tj)
+
+n = 1700
+x = rng.random((n, 3))
+f = np.sin(3 * x[:, 0]) + x[:, 1] * x[:, 2]
+it = mgpi.Interpolator(mgpi.SquaredExponentialKernel(1.0, 0.2, 0.2, 0.2), nugget=mgpi.WhiteNoiseKernel(1e-2), context=ctx)
+K = mgpi.Interpolator._x2cov(x, x, it.kernel + it.nugget)
+alpha = it.compress(x, f)
+assert np.max(np.abs(K @ alpha - f)) < 1e-10 * np.max(np.abs(f))
+mean, var = it.condition_diag(x[:300] + 0.01, x, f)
+ll = it.loglikelihood(x, f)
+s, logdet = np.linalg.slogdet(K)
+assert abs(ll - (-0.5 * f @ alpha - 0.5 * logdet - 0.5 * n * np.log(2 * np.pi))) < 1e-9 * abs(ll)
+assert np.all(var > 0) and np.all(var < 1.0)
+ctx.trim()
+print('VARIANT-OK', flush=True)
