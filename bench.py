@@ -294,10 +294,12 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': tflops_syrk, 'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': tflops_syrk / PEAK_FP64_MFMA_TFLOPS,
                          'traffic': load_traffic(args.workload) if not distributed else None,
-                         'kernel': 'gemm_f64_kernel<128,128,NT%s> (Cholesky trailing update%s)' % ((',lower', ', syrk') if not distributed else ('', ', rank 0 local blocks')),
+                         'kernel': 'gemm_f64_pipe_kernel<NT%s> (Cholesky trailing update%s)' % ((',lower', ', syrk') if not distributed else ('', ', rank 0 local blocks')),
                          'launches': int(syrk_launches), 'avg_launch_ms': syrk_ms / max(1, syrk_launches),
                          'algorithmic_flops_per_step': tr_flops,
-                         'note': 'timed region runs with look-ahead: a panel factorisation shares the GPU with this kernel',
+                         'note': 'timed region runs with look-ahead: the column update of the next panel (same gemm family, '
+                                 'other stream) and its factorisation share the GPU with this kernel; isolated_* = the '
+                                 'same launches with the look-ahead off',
                          'isolated_achieved': iso, 'isolated_frac': (iso / PEAK_FP64_MFMA_TFLOPS) if iso else None},
             'stages_ms_per_step': {'potrf': potrf_ms / args.steps, 'potrf_trailing_update': syrk_ms / args.steps,
                                    'potrf_next_panel_column_update': colupd_ms / args.steps,

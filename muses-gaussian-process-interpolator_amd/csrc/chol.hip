@@ -315,14 +315,21 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
         return 0;
     };
 
-    // Look-ahead (depth 1): after panel k, first update ONLY the block column of panel k+1, then factor panel k+1
-    // on the second (high-priority) stream while the rest of the trailing update of panel k runs on the main
-    // stream.  The two touch disjoint columns; the next step's updates wait for the panel through an event.
+    // Look-ahead (depth 1).  The trailing update of panel k is split by columns: the block column of panel k+1, and the
+    // rest.  The column update and then the factorisation of panel k+1 run on the second (high-priority) stream, the
+    // rest on the main stream AT THE SAME TIME - the two write disjoint columns and both only read panel k.  So the main
+    // stream sees one big lower-triangular update after another, and the chain  column update -> panel  has a whole
+    // trailing update to hide behind.  (The first version ran the column update on the main stream in front of the
+    // rest: 11 ms of skinny gemms per C3 factorisation on the critical path, plus a drain/refill of the chip between
+    // the two launches of every step.)  Events: ev_upd = "the rest of step k-1 is done" (its columns include the one
+    // the second stream updates next), ev_panel = "panel k+1 is factored".
     hipStream_t main_stream = ctx->stream;
     const bool lookahead = ctx->stream2 != nullptr && !ctx->no_lookahead;
     mgpi_prof_begin(ctx, 1);
     MGPI_TRY(factor_panel(0, (pn < nb) ? pn : nb));
     mgpi_prof_end(ctx, 1);
+    if (lookahead) MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
+    bool panel_on_side = false;                                  // is the current panel k the product of stream2?
     for (int64_t r0 = 0; r0 < pn; r0 += nb) {
         const int64_t w = (pn - r0 < nb) ? (pn - r0) : nb;   // panel k (already factored)
         const int64_t t = pn - r0 - w;                        // trailing size
@@ -330,37 +337,50 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
         const int64_t r1 = r0 + w;
         const int64_t w1 = (pn - r1 < nb) ? (pn - r1) : nb;   // panel k+1
         const double* P = A + r1 * lda + r0;                  // rows r1.., the w columns of panel k
-        // (1) block column of the next panel: A[r1:pn, r1:r1+w1] -= P P[0:w1]^T
-        mgpi_prof_begin(ctx, 3);
-        MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, t, w1, w, P, lda, P, lda, A + r1 * lda + r1, lda));
-        mgpi_prof_end(ctx, 3);
-        // (2) factor panel k+1
+        const int64_t t2 = t - w1;
         if (lookahead) {
-            MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
+            // main stream: wait for panel k (before ev_panel is recorded again below)
+            if (panel_on_side) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
+            // second stream, enqueued first so that it gets the first free CUs:
+            //   A[r1:pn, r1:r1+w1] -= P P[0:w1]^T, then factor panel k+1
             MGPI_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_upd, 0));
             ctx->stream = ctx->stream2;
-            ctx->lean = 1;
-            const int rc = factor_panel(r1, w1);
-            ctx->lean = 0;
+            mgpi_prof_begin(ctx, 3);
+            int rc = mgpi_launch_gemm(ctx, 0, 0, 0, t, w1, w, P, lda, P, lda, A + r1 * lda + r1, lda);
+            mgpi_prof_end(ctx, 3);
+            if (rc == 0) {
+                ctx->lean = 1;
+                rc = factor_panel(r1, w1);
+                ctx->lean = 0;
+            }
             ctx->stream = main_stream;
             MGPI_TRY(rc);
             MGPI_HIP_TRY(hipEventRecord(ctx->ev_panel, ctx->stream2));
+            panel_on_side = true;
+            // main stream: the rest of the trailing update (lower tiles): A[r2:pn, r2:pn] -= P[w1:] P[w1:]^T
+            if (t2 > 0) {
+                mgpi_prof_begin(ctx, 0);
+                const double* P2 = P + w1 * lda;
+                MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 1, t2, t2, w, P2, lda, P2, lda, A + (r1 + w1) * lda + (r1 + w1), lda));
+                mgpi_prof_end(ctx, 0);
+            }
+            MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
         } else {
+            mgpi_prof_begin(ctx, 3);
+            MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, t, w1, w, P, lda, P, lda, A + r1 * lda + r1, lda));
+            mgpi_prof_end(ctx, 3);
             mgpi_prof_begin(ctx, 1);
             MGPI_TRY(factor_panel(r1, w1));
             mgpi_prof_end(ctx, 1);
+            if (t2 > 0) {
+                mgpi_prof_begin(ctx, 0);
+                const double* P2 = P + w1 * lda;
+                MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 1, t2, t2, w, P2, lda, P2, lda, A + (r1 + w1) * lda + (r1 + w1), lda));
+                mgpi_prof_end(ctx, 0);
+            }
         }
-        // (3) the rest of the trailing update (lower tiles): A[r2:pn, r2:pn] -= P[w1:] P[w1:]^T
-        const int64_t t2 = t - w1;
-        if (t2 > 0) {
-            mgpi_prof_begin(ctx, 0);
-            const double* P2 = P + w1 * lda;
-            MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 1, t2, t2, w, P2, lda, P2, lda, A + (r1 + w1) * lda + (r1 + w1), lda));
-            mgpi_prof_end(ctx, 0);
-        }
-        // (4) the next step needs panel k+1
-        if (lookahead) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
     }
+    if (lookahead && panel_on_side) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
 
     mgpi_prof_end(ctx, 2);
 
