@@ -419,40 +419,50 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
             }
             return 0;
         };
-        // look-ahead as in the factorisation: the rows of the next outer block are updated first and solved on the
-        // second stream (lean kernels) while the rest of the update runs on the main stream
+        // look-ahead as in the factorisation: the update of the next outer block's rows and then their solve run on
+        // the second stream (the solve with lean kernels) while the update of all the rows below runs on the main
+        // stream at the same time - disjoint rows of B, both only read the solved rows of block k
         hipStream_t main_stream = ctx->stream;
         const bool lookahead = ctx->stream2 != nullptr && !ctx->no_lookahead;
         MGPI_TRY(solve_diag_block(0, (pn < nb) ? pn : nb));
+        if (lookahead) MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
+        bool block_on_side = false;
         for (int64_t r0 = 0; r0 < pn; r0 += nb) {
             const int64_t w = (pn - r0 < nb) ? (pn - r0) : nb;
             const int64_t t = pn - r0 - w;
             if (t <= 0) break;
             const int64_t r1 = r0 + w;
             const int64_t w1 = (pn - r1 < nb) ? (pn - r1) : nb;
-            // (1) B[r1:r1+w1,:] -= L[r1:r1+w1, r0:r0+w] * B[r0:r0+w,:]
-            MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, w1, nc, w, L + r1 * lda + r0, lda, B + r0 * ldb, ldb, B + r1 * ldb, ldb));
-            // (2) solve the next diagonal block
+            const int64_t t2 = t - w1;
             if (lookahead) {
-                MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
-                MGPI_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_upd, 0));
+                if (block_on_side) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));   // rows of block k solved
+                // second stream: B[r1:r1+w1,:] -= L[r1:r1+w1, r0:r0+w] * B[r0:r0+w,:], then solve that block
+                MGPI_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_upd, 0));                        // update k-1 of these rows done
                 ctx->stream = ctx->stream2;
-                ctx->lean = 1;
-                const int rc = solve_diag_block(r1, w1);
-                ctx->lean = 0;
+                int rc = mgpi_launch_gemm(ctx, 0, 1, 0, w1, nc, w, L + r1 * lda + r0, lda, B + r0 * ldb, ldb, B + r1 * ldb, ldb);
+                if (rc == 0) {
+                    ctx->lean = 1;
+                    rc = solve_diag_block(r1, w1);
+                    ctx->lean = 0;
+                }
                 ctx->stream = main_stream;
                 MGPI_TRY(rc);
                 MGPI_HIP_TRY(hipEventRecord(ctx->ev_panel, ctx->stream2));
+                block_on_side = true;
+                // main stream: the remaining rows  B[r1+w1:,:] -= L[r1+w1:, r0:r0+w] * B[r0:r0+w,:]
+                if (t2 > 0)
+                    MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, t2, nc, w, L + (r1 + w1) * lda + r0, lda, B + r0 * ldb, ldb,
+                                              B + (r1 + w1) * ldb, ldb));
+                MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
             } else {
+                MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, w1, nc, w, L + r1 * lda + r0, lda, B + r0 * ldb, ldb, B + r1 * ldb, ldb));
                 MGPI_TRY(solve_diag_block(r1, w1));
+                if (t2 > 0)
+                    MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, t2, nc, w, L + (r1 + w1) * lda + r0, lda, B + r0 * ldb, ldb,
+                                              B + (r1 + w1) * ldb, ldb));
             }
-            // (3) the remaining rows: B[r1+w1:,:] -= L[r1+w1:, r0:r0+w] * B[r0:r0+w,:]
-            const int64_t t2 = t - w1;
-            if (t2 > 0)
-                MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, t2, nc, w, L + (r1 + w1) * lda + r0, lda, B + r0 * ldb, ldb,
-                                          B + (r1 + w1) * ldb, ldb));
-            if (lookahead) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
         }
+        if (lookahead && block_on_side) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
     } else {
         const int64_t nblk = (pn + nb - 1) / nb;
         for (int64_t b = nblk - 1; b >= 0; --b) {
