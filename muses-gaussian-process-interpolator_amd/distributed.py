@@ -315,7 +315,8 @@ class DistributedGP(object):
         self.A = None
         self.logdet = None
         self.alpha = None
-        self.trailing_flops = 0.0     # algorithmic flops of this rank's trailing updates (bench.py roofline)
+        self.trailing_flops = 0.0   # algorithmic flops of this rank's trailing updates on the main stream (bench.py roofline)
+        self.column_flops = 0.0     # ... and of its next-panel column updates on the look-ahead stream
         self.row_panels = None        # L[I][k] for the local block rows, every block step k (filled by factor)
         self._row_panel_offset = None
 
@@ -438,20 +439,25 @@ class DistributedGP(object):
             return
         be.gemm_nt_stair(self.A[i0 * nb:, c_lo * nb:c_hi * nb], pan['wrow'], pan['wcol'][(c_lo - j0) * nb:(c_hi - j0) * nb],
                          g.P, g.p, g.Q, g.q, i0, c_lo, nb)
-        for jl in range(c_lo, c_hi):                             # flop bookkeeping only (bench.py roofline)
+        flops = 0.0                                              # flop bookkeeping only (bench.py roofline)
+        for jl in range(c_lo, c_hi):
             J = self.col_blocks[jl]
             il = self._first_local(self.row_blocks, J - 1)
             if il < len(self.row_blocks):
                 rows = self.mloc - il * nb
                 diag = nb if self.row_blocks[il] == J else 0      # a diagonal block counts as its lower half
-                self.trailing_flops += 2.0 * (rows - diag) * nb * nb + diag * (nb + 1.0) * nb
+                flops += 2.0 * (rows - diag) * nb * nb + diag * (nb + 1.0) * nb
+        if be is self.be:
+            self.trailing_flops += flops                         # launches timed by the main context's profile slot 0
+        else:
+            self.column_flops += flops                           # next-panel column updates on the look-ahead stream
 
     def factor(self, lookahead=None):
         """2-D block-cyclic right-looking Cholesky.  With look-ahead (default; MGPI_DIST_LOOKAHEAD=0 turns it off)
-        block step k first updates only the block column of step k+1, then step k+1's panel work - diagonal
-        factorisation, panel solve and all its broadcasts - runs on a second stream while the rest of the trailing
-        update of step k runs on the main stream, so the xGMI transfers and the latency-bound panel hide behind
-        the MFMA work.  Every rank issues the same collectives in the same order in both modes."""
+        the update of the block column of step k+1 and then step k+1's panel work - diagonal factorisation, panel
+        solve and all its broadcasts - run on a second stream while the rest of the trailing update of step k runs on
+        the main stream, so the xGMI transfers and the latency-bound panel hide behind the MFMA work.  Every rank
+        issues the same collectives in the same order in both modes."""
         import os
         g, be, nb = self.g, self.be, self.nb
         if lookahead is None:
@@ -490,15 +496,16 @@ class DistributedGP(object):
                     pan = self._panel(k + 1, be, bufs[(k + 1) % 2])
                     note(pan)
                 continue
-            # (a) the block column of the next panel first
-            if own_next:
-                self._update(pan, j0, j0 + 1, be)
+            # Everything queued on the main stream so far (the rest of step k-1 included) is what the side stream has
+            # to wait for.  (a) side stream, queued first: the block column of the next panel, then that panel - its
+            # diagonal factorisation, panel solve and all of its broadcasts; (b) main stream, at the same time: the
+            # rest of the trailing update.  The two write disjoint block columns and both only read panel k.
             ready = be.record()
-            # (b) the rest of the trailing update, queued on the main stream
-            self._update(pan, j0 + 1 if own_next else j0, ncols, be)
-            # (c) meanwhile the next panel on the side stream (it touches block column k+1 only)
             with be.on_side(ready):
+                if own_next:
+                    self._update(pan, j0, j0 + 1, side)
                 nxt_pan = self._panel(k + 1, side, bufs[(k + 1) % 2])
+            self._update(pan, j0 + 1 if own_next else j0, ncols, be)
             be.join_side()
             note(nxt_pan)
             pan = nxt_pan
