@@ -788,30 +788,41 @@ __global__ __launch_bounds__(256) void trsv_update_bwd_kernel(const double* __re
     if (wave == 0 && j < cols) y[j] -= part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
 }
 
+static void launch_trsv_update(hipStream_t stream, const double* L, int64_t lda, double* v, int64_t r0, int w, int64_t first,
+                               int64_t count, int trans) {
+    if (count <= 0) return;
+    if (!trans) {    // rows [first, first + count) below the block:  v[i] -= L[i][r0:r0+w] y
+        int64_t blocks = (count + 3) / 4;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(trsv_update_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, L + first * lda + r0, lda, v + r0,
+                           w, v + first, count);
+    } else {         // columns [first, first + count) left of the block:  v[j] -= L[r0:r0+w][j]^T x
+        hipLaunchKernelGGL(trsv_update_bwd_kernel, dim3((unsigned)((count + IB - 1) / IB)), dim3(256), 0, stream,
+                           L + r0 * lda + first, lda, v + r0, w, v + first, count);
+    }
+}
+
+// L y = f, then L^T x = y, one right-hand side.  Per outer block: a one-workgroup substitution kernel on the diagonal
+// block (the chain) and a wide gemv on everything that block feeds (HBM-bound), all on one stream.  Splitting the gemv
+// so that only the next block's entries stay on the chain and the rest runs on the second stream was measured and
+// dropped: the event record/wait pairs it puts on the chain cost more than the ~15 us gemv they take off it
+// (11.4 vs 10.3 ms at N = 32768, 2.55 vs 2.15 ms at N = 8192).
 static int trsv_pair(mgpi_ctx* ctx, const mgpi_mat* Lm, double* v) {
     const int64_t pn = Lm->prows <= Lm->pcols ? Lm->prows : mgpi_roundup(Lm->rows, IB);
     const int64_t lda = Lm->ld;
     const int64_t nb = ctx->nb;
     const double* L = Lm->d;
-    for (int64_t r0 = 0; r0 < pn; r0 += nb) {   // L y = f
+    const int64_t nblk = (pn + nb - 1) / nb;
+    for (int64_t r0 = 0; r0 < pn; r0 += nb) {
         const int w = (int)((pn - r0 < nb) ? (pn - r0) : nb);
         launch_trsv_diag(ctx, L + r0 * lda + r0, lda, v + r0, w, 0);
-        const int64_t rows = pn - r0 - w;
-        if (rows > 0) {
-            int64_t blocks = (rows + 3) / 4;
-            if (blocks > 2048) blocks = 2048;
-            hipLaunchKernelGGL(trsv_update_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-                               L + (r0 + w) * lda + r0, lda, v + r0, w, v + r0 + w, rows);
-        }
+        launch_trsv_update(ctx->stream, L, lda, v, r0, w, r0 + w, pn - r0 - w, 0);
     }
-    const int64_t nblk = (pn + nb - 1) / nb;
-    for (int64_t b = nblk - 1; b >= 0; --b) {   // L^T x = y
+    for (int64_t b = nblk - 1; b >= 0; --b) {
         const int64_t r0 = b * nb;
         const int w = (int)((pn - r0 < nb) ? (pn - r0) : nb);
         launch_trsv_diag(ctx, L + r0 * lda + r0, lda, v + r0, w, 1);
-        if (r0 > 0)
-            hipLaunchKernelGGL(trsv_update_bwd_kernel, dim3((unsigned)((r0 + IB - 1) / IB)), dim3(256), 0, ctx->stream,
-                               L + r0 * lda, lda, v + r0, w, v, r0);
+        launch_trsv_update(ctx->stream, L, lda, v, r0, w, 0, r0, 1);
     }
     MGPI_HIP_TRY(hipGetLastError());
     return 0;

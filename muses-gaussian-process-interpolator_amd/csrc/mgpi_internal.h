@@ -25,7 +25,7 @@ struct mgpi_ctx {
     int nb;                       // outer Cholesky block
     hipStream_t stream;           // where launchers enqueue (the main stream, except during a look-ahead panel)
     hipStream_t stream2;          // high-priority stream of the look-ahead panel factorisation
-    hipEvent_t ev_upd, ev_panel;  // next-panel column updated / next panel factored
+    hipEvent_t ev_upd, ev_panel;  // main-stream update of a step done / look-ahead stream's panel (block) done
     int no_lookahead;             // MGPI_NO_LOOKAHEAD=1 (developer switch)
     int lean;                     // launch gemms as 64x64 tiles (32 KB LDS, < 104 VGPRs): they can then start next to
                                   // two resident trailing-update workgroups during the look-ahead
