@@ -592,15 +592,14 @@ __global__ __launch_bounds__(256) void trsv_diag_bwd_kernel(const double* __rest
 // the part solved before s, the next diagonal tile and the 64 x 64 coupling tile (into registers).  After the barrier
 // only a register-resident 64 x 64 gemv with the fresh y_s remains.  Same arithmetic, different summation order.
 // Measured (N = 32768, rocprofv3): forward 94 -> 72 us per diagonal block, backward 79 -> 52 us; potrs 13.4 -> 10.3 ms.
-// Two further variants were measured and dropped: lanes along the row with shuffle reductions for the forward
-// partial sums (coalesced, but 16 accumulators x 6 shuffles after the barrier: 174 us), and a diagonal tile
-// pre-scaled by 1/T[k][k] to shorten the substitution step to readlane -> fma (no change: the sub-block time is set
-// by one HBM round trip of the streaming waves, not by the substitution; unrolling their load loops changed nothing).
+// A variant with lanes along the row and shuffle reductions for the forward partial sums (coalesced, but 16
+// accumulators x 6 shuffles after the barrier) was measured and dropped: 174 us per diagonal block.
 #define TRSV_PIPE_MAXW 1024
 __global__ __launch_bounds__(320) void trsv_diag_fwd_pipe_kernel(const double* __restrict__ L, int64_t lda,
                                                                  double* __restrict__ y, int w) {
     __shared__ double ys[TRSV_PIPE_MAXW];
-    __shared__ double Tt[IB][IB];          // current diagonal tile, TRANSPOSED: Tt[k][r] = T[r][k] (conflict-free by lane)
+    __shared__ double Tt[IB][IB + 1];      // current diagonal tile, TRANSPOSED: Tt[k][r] = T[r][k]; the pad keeps the
+                                           // transposing writes (lane -> first index) off a single bank
     __shared__ double part[4][IB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool solver = wave == 0;
@@ -621,14 +620,17 @@ __global__ __launch_bounds__(320) void trsv_diag_fwd_pipe_kernel(const double* _
         const bool more = c1 < w;
         double tn[IB * IB / 256], xr[16], snext = 0.0;
         if (solver) {
+            // b_r -= (T[r][k] / T[k][k]) * b_k : the scaled coefficient does not depend on the running b, so the chain
+            // per step is readlane -> fma (the dependent fp64 latency is 32 cycles per op); y = b / diag at the end
             double b = ys[c0 + lane] - pend;
             const double rd = 1.0 / Tt[lane][lane];
-#pragma unroll 4
+#pragma unroll 8
             for (int k = 0; k < IB; ++k) {
-                const double yk = readlane_f64(b, k) * readlane_f64(rd, k);
-                b = (lane == k) ? yk : ((lane > k) ? fma(-Tt[k][lane], yk, b) : b);
+                const double coef = Tt[k][lane] * readlane_f64(rd, k);
+                const double bk = readlane_f64(b, k);
+                b = (lane > k) ? fma(-coef, bk, b) : b;
             }
-            ys[c0 + lane] = b;
+            ys[c0 + lane] = b * rd;
         } else if (more) {
 #pragma unroll
             for (int u = 0; u < IB * IB / 256; ++u) {          // next diagonal tile
@@ -694,12 +696,13 @@ __global__ __launch_bounds__(320) void trsv_diag_bwd_pipe_kernel(const double* _
         if (solver) {
             double b = ys[c0 + lane] - pend;
             const double rd = 1.0 / Tn[lane][lane];
-#pragma unroll 4
+#pragma unroll 8
             for (int k = IB - 1; k >= 0; --k) {
-                const double xk = readlane_f64(b, k) * readlane_f64(rd, k);
-                b = (lane == k) ? xk : ((lane < k) ? fma(-Tn[k][lane], xk, b) : b);
+                const double coef = Tn[k][lane] * readlane_f64(rd, k);       // off the chain (see the forward kernel)
+                const double bk = readlane_f64(b, k);
+                b = (lane < k) ? fma(-coef, bk, b) : b;
             }
-            ys[c0 + lane] = b;
+            ys[c0 + lane] = b * rd;
         } else if (more) {
 #pragma unroll
             for (int u = 0; u < IB * IB / 256; ++u) {          // next diagonal tile
@@ -744,12 +747,30 @@ static void launch_trsv_diag(mgpi_ctx* ctx, const double* L, int64_t lda, double
     }
 }
 
+// L2 warm-up for the NEXT diagonal block: the substitution kernel that follows is one workgroup, which the dispatcher
+// places on XCD 0, and what it waits for per sub-block is one HBM round trip.  The workgroups of the wide gemv that
+// land on XCD 0 (blockIdx % 8 == 0) touch one double per 128-byte line of that block's lower triangle, so that the
+// lines sit in XCD 0's L2 when the substitution starts.  The loaded values feed a store that never executes.
+__device__ __forceinline__ void trsv_warm_l2(const double* __restrict__ nxt, int64_t lda, int wn, double* sink) {
+    if (nxt == nullptr || (blockIdx.x & 7) != 0) return;
+    const int64_t g = blockIdx.x >> 3, ng = (gridDim.x + 7) >> 3;
+    const int64_t lines_per_row = (wn + 15) / 16;
+    double acc = 0.0;
+    for (int64_t id = g * 256 + threadIdx.x; id < (int64_t)wn * lines_per_row; id += ng * 256) {
+        const int64_t r = id / lines_per_row, c = (id % lines_per_row) * 16;
+        if (c <= r) acc += nxt[r * lda + c];
+    }
+    if (acc == 1.2345678e-300) sink[0] = acc;
+}
+
 // forward update: f[i] -= sum_{k<w} Lp[i][k] y[k]  for the rows below the block; one wave per row
 __global__ __launch_bounds__(256) void trsv_update_fwd_kernel(const double* __restrict__ Lp, int64_t lda,
                                                               const double* __restrict__ y, int w,
-                                                              double* __restrict__ f, int64_t rows) {
+                                                              double* __restrict__ f, int64_t rows,
+                                                              const double* __restrict__ warm, int warm_w) {
     __shared__ double ys[4096];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    trsv_warm_l2(warm, lda, warm_w, f);
     for (int i = tid; i < w; i += 256) ys[i] = y[i];
     __syncthreads();
     for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
@@ -767,10 +788,12 @@ __global__ __launch_bounds__(256) void trsv_update_fwd_kernel(const double* __re
 // backward update: y[j] -= sum_{i<w} Lb[i][j] x[i]  for the columns left of the block; 64 columns per workgroup
 __global__ __launch_bounds__(256) void trsv_update_bwd_kernel(const double* __restrict__ Lb, int64_t lda,
                                                               const double* __restrict__ x, int w,
-                                                              double* __restrict__ y, int64_t cols) {
+                                                              double* __restrict__ y, int64_t cols,
+                                                              const double* __restrict__ warm, int warm_w) {
     __shared__ double xs[4096];
     __shared__ double part[4][IB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    trsv_warm_l2(warm, lda, warm_w, y);
     for (int i = tid; i < w; i += 256) xs[i] = x[i];
     __syncthreads();
     const int64_t j = (int64_t)blockIdx.x * IB + lane;
@@ -789,16 +812,16 @@ __global__ __launch_bounds__(256) void trsv_update_bwd_kernel(const double* __re
 }
 
 static void launch_trsv_update(hipStream_t stream, const double* L, int64_t lda, double* v, int64_t r0, int w, int64_t first,
-                               int64_t count, int trans) {
+                               int64_t count, int trans, const double* warm = nullptr, int warm_w = 0) {
     if (count <= 0) return;
     if (!trans) {    // rows [first, first + count) below the block:  v[i] -= L[i][r0:r0+w] y
         int64_t blocks = (count + 3) / 4;
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(trsv_update_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, L + first * lda + r0, lda, v + r0,
-                           w, v + first, count);
+                           w, v + first, count, warm, warm_w);
     } else {         // columns [first, first + count) left of the block:  v[j] -= L[r0:r0+w][j]^T x
         hipLaunchKernelGGL(trsv_update_bwd_kernel, dim3((unsigned)((count + IB - 1) / IB)), dim3(256), 0, stream,
-                           L + r0 * lda + first, lda, v + r0, w, v + first, count);
+                           L + r0 * lda + first, lda, v + r0, w, v + first, count, warm, warm_w);
     }
 }
 
@@ -816,13 +839,16 @@ static int trsv_pair(mgpi_ctx* ctx, const mgpi_mat* Lm, double* v) {
     for (int64_t r0 = 0; r0 < pn; r0 += nb) {
         const int w = (int)((pn - r0 < nb) ? (pn - r0) : nb);
         launch_trsv_diag(ctx, L + r0 * lda + r0, lda, v + r0, w, 0);
-        launch_trsv_update(ctx->stream, L, lda, v, r0, w, r0 + w, pn - r0 - w, 0);
+        const int64_t r1 = r0 + w;
+        const int w1 = (int)((pn - r1 < nb) ? (pn - r1) : nb);
+        launch_trsv_update(ctx->stream, L, lda, v, r0, w, r1, pn - r1, 0, w1 > 0 ? L + r1 * lda + r1 : nullptr, w1);
     }
     for (int64_t b = nblk - 1; b >= 0; --b) {
         const int64_t r0 = b * nb;
         const int w = (int)((pn - r0 < nb) ? (pn - r0) : nb);
         launch_trsv_diag(ctx, L + r0 * lda + r0, lda, v + r0, w, 1);
-        launch_trsv_update(ctx->stream, L, lda, v, r0, w, 0, r0, 1);
+        const int wp = (int)((r0 < nb) ? r0 : nb);
+        launch_trsv_update(ctx->stream, L, lda, v, r0, w, 0, r0, 1, wp > 0 ? L + (r0 - wp) * lda + (r0 - wp) : nullptr, wp);
     }
     MGPI_HIP_TRY(hipGetLastError());
     return 0;
@@ -900,13 +926,13 @@ extern "C" int mgpi_gemv_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* x
             int64_t blocks = (m + 3) / 4;
             if (blocks > 2048) blocks = 2048;
             hipLaunchKernelGGL(trsv_update_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, A->d + c0, A->ld,
-                               x->d + c0, w, y->d, m);
+                               x->d + c0, w, y->d, m, (const double*)nullptr, 0);
         }
     } else {
         for (int64_t r0 = 0; r0 < m; r0 += 4096) {
             const int w = (int)((m - r0 < 4096) ? (m - r0) : 4096);
             hipLaunchKernelGGL(trsv_update_bwd_kernel, dim3((unsigned)((k + IB - 1) / IB)), dim3(256), 0, ctx->stream,
-                               A->d + r0 * A->ld, A->ld, x->d + r0, w, y->d, k);
+                               A->d + r0 * A->ld, A->ld, x->d + r0, w, y->d, k, (const double*)nullptr, 0);
         }
     }
     MGPI_HIP_TRY(hipGetLastError());
