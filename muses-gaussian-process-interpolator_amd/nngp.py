@@ -221,6 +221,16 @@ class NearestNeighborInterpolator(Interpolator):
         mean, diag = self.condition_diag(target_x, source_x, source_f, verbose=verbose, Verbose=Verbose)
         return mean, np.diag(diag)
 
+    def rvs(self, target_x, source_x, source_f, size=1, rng=None):
+        """`size` realisations of f(target_x) | source_f.  The reference's rvs (interpolators.py:306-324) draws from
+        whatever ``self.condition`` returns; for the NNGP that covariance is diagonal, so the draw is mean + z * sqrt(var)
+        with independent standard normals z (numpy's, like Interpolator.rvs; `rng` may be a numpy Generator)."""
+        mean, diag = self.condition_diag(target_x, source_x, source_f)
+        normal = rng.standard_normal if rng is not None else np.random.standard_normal
+        return mean + normal((int(size), len(mean))) * np.sqrt(diag)
+
+    sample = rvs
+
     def compress(self, source_x, source_f, verbose=False, Verbose=False):
         raise NotImplementedError('the reference leaves NearestNeighborInterpolator.compress unimplemented '
                                   '(mgpi/interpolators.py:888-899); use condition / condition_diag')

@@ -138,6 +138,20 @@ def test_nngp_api_surface_and_errors():
         mgpi.NearestNeighborInterpolator(kern, num_neighbors=10).loglikelihood(dup, np.arange(11.0))
 
 
+def test_nngp_rvs_draws_from_the_diagonal_conditional():
+    rng = np.random.default_rng(4)
+    x = rng.random((400, 2))
+    f = np.sin(4 * x[:, 0]) + x[:, 1]
+    xs = rng.random((6, 2))
+    nn = mgpi.NearestNeighborInterpolator(mgpi.SquaredExponentialKernel(1.0, 0.2, 0.2), nugget=mgpi.WhiteNoiseKernel(5e-2))
+    mean, var = nn.condition_diag(xs, x, f)
+    draws = nn.rvs(xs, x, f, size=20000, rng=np.random.default_rng(9))
+    assert draws.shape == (20000, 6) and nn.sample.__func__ is nn.rvs.__func__
+    assert np.all(np.abs(draws.mean(axis=0) - mean) < 5 * np.sqrt(var / 20000))
+    assert np.all(np.abs(draws.var(axis=0) / var - 1) < 0.05)
+    assert np.max(np.abs(np.corrcoef(draws.T) - np.eye(6))) < 0.04
+
+
 def test_nngp_hyperparameter_logprob_reuses_neighbors():
     rng = np.random.default_rng(8)
     x = rng.random((600, 2))
