@@ -207,6 +207,9 @@ int  mgpi_ctx_set_profile(mgpi_ctx* ctx, int on);
 /* which: 0 = trailing update (lower syrk launches), 1 = panel (potf2+trsm+inner gemm; only when look-ahead is off),
  * 2 = whole potrf, 3 = look-ahead update of the next panel's block column; ms and launches */
 int  mgpi_ctx_get_profile(mgpi_ctx* ctx, int which, double* ms, int64_t* launches);
+/* algorithmic flops of the launches recorded in slot `which` since profiling was switched on: for slot 0 the sum of
+ * t (t + 1) K over the lower-triangular trailing updates (t rows, contraction length K) */
+int  mgpi_ctx_get_profile_flops(mgpi_ctx* ctx, int which, double* flops);
 
 #ifdef __cplusplus
 }

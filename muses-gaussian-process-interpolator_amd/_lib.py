@@ -98,6 +98,7 @@ _SIGNATURES = {
     'mgpi_ctx_set_lookahead': (ctypes.c_int, [_vp, ctypes.c_int]),
     'mgpi_ctx_set_profile': (ctypes.c_int, [_vp, ctypes.c_int]),
     'mgpi_ctx_get_profile': (ctypes.c_int, [_vp, ctypes.c_int, c_double_p, ctypes.POINTER(c_int64)]),
+    'mgpi_ctx_get_profile_flops': (ctypes.c_int, [_vp, ctypes.c_int, c_double_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
@@ -292,6 +293,11 @@ class Context(object):
         n = c_int64(0)
         check(self.lib.mgpi_ctx_get_profile(self.handle, int(which), ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
+
+    def get_profile_flops(self, which):
+        flops = ctypes.c_double(0.0)
+        check(self.lib.mgpi_ctx_get_profile_flops(self.handle, int(which), ctypes.byref(flops)))
+        return flops.value
 
     def close(self):
         if self.handle is not None:

@@ -315,44 +315,74 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
         return 0;
     };
 
-    // Look-ahead (depth 1).  The trailing update of panel k is split by columns: the block column of panel k+1, and the
-    // rest.  The column update and then the factorisation of panel k+1 run on the second (high-priority) stream, the
-    // rest on the main stream AT THE SAME TIME - the two write disjoint columns and both only read panel k.  So the main
-    // stream sees one big lower-triangular update after another, and the chain  column update -> panel  has a whole
-    // trailing update to hide behind.  (The first version ran the column update on the main stream in front of the
-    // rest: 11 ms of skinny gemms per C3 factorisation on the critical path, plus a drain/refill of the chip between
-    // the two launches of every step.)  Events: ev_upd = "the rest of step k-1 is done" (its columns include the one
-    // the second stream updates next), ev_panel = "panel k+1 is factored".
+    // Two-level blocking.  The panels are nb wide (the blocked algorithm of the reference configuration), but while
+    // the trailing matrix is large the trailing update is applied once per SUPER-PANEL of MGPI_SUPER_PANELS (default
+    // 2) panels, i.e. with a contraction length of 1024 instead of 512: the C tiles then cross HBM half as often and
+    // the tile prologue/epilogue is amortised over twice the MFMA work.  Measured on the lower-syrk launch alone
+    // (tools/syrk_only.py n reps K): 66.9 / 69.5 / 70.6 TFLOP/s at 32256 rows for K = 512 / 1024 / 2048, 57.7 / 63.2 /
+    // 68.9 at 16384.  Inside a super-panel the factorisation is the same right-looking nb-panel algorithm restricted
+    // to the super-panel's columns.  In the whole factorisation the gain is small, because the work moved out of the
+    // big update (wider column updates, the skinny updates inside the super-panel) runs on the look-ahead stream and
+    // lengthens the chain the next big update waits for: potrf at N = 32768 is 195.2 ms with 1 panel per update,
+    // 193.1 with 2, 195.5 with 3, 195.4-199 with 4 (bench.py, 3 steps each).  Below MGPI_SUPER_MIN trailing rows the
+    // width drops back to one panel.
+    //
+    // Look-ahead (depth 1, in units of super-panels).  The trailing update of super-panel k is split by columns:
+    // the block columns of super-panel k+1, and the rest.  The column update and then the factorisation of
+    // super-panel k+1 run on the second (high-priority) stream, the rest on the main stream AT THE SAME TIME - the two
+    // write disjoint columns and both only read super-panel k.  So the main stream sees one big lower-triangular
+    // update after another.  Events: ev_upd = "the rest of step k-1 is done" (its columns include the ones the second
+    // stream updates next), ev_panel = "super-panel k+1 is factored".
+    auto factor_super = [&](int64_t c0, int64_t wc, bool on_side) -> int {
+        for (int64_t p0 = c0; p0 < c0 + wc; p0 += nb) {
+            const int64_t w = (c0 + wc - p0 < nb) ? (c0 + wc - p0) : nb;
+            ctx->lean = on_side ? 1 : 0;
+            int rc = factor_panel(p0, w);
+            ctx->lean = 0;
+            if (rc) return rc;
+            const int64_t p1 = p0 + w, rem = c0 + wc - p1, t = pn - p1;
+            if (rem > 0 && t > 0)    // the rest of the super-panel's columns: A[p1:pn, p1:c0+wc] -= P P[0:rem]^T
+                MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, t, rem, w, A + p1 * lda + p0, lda, A + p1 * lda + p0, lda,
+                                          A + p1 * lda + p1, lda));
+        }
+        return 0;
+    };
+    static const int64_t super_min = getenv("MGPI_SUPER_MIN") ? atoll(getenv("MGPI_SUPER_MIN")) : 14336;
+    static const int64_t super_panels = getenv("MGPI_SUPER_PANELS") ? atoll(getenv("MGPI_SUPER_PANELS")) : 2;
+    auto super_width = [&](int64_t c0) -> int64_t {      // width of the super-panel that starts at column c0
+        const int64_t left = pn - c0;
+        // the very first one has nothing to hide behind: keep it one panel wide
+        int64_t wc = (c0 > 0 && left - super_panels * nb >= super_min) ? super_panels * nb : nb;
+        return wc < left ? wc : left;
+    };
+
     hipStream_t main_stream = ctx->stream;
     const bool lookahead = ctx->stream2 != nullptr && !ctx->no_lookahead;
+    int64_t wc = super_width(0);
     mgpi_prof_begin(ctx, 1);
-    MGPI_TRY(factor_panel(0, (pn < nb) ? pn : nb));
+    MGPI_TRY(factor_super(0, wc, false));
     mgpi_prof_end(ctx, 1);
     if (lookahead) MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
-    bool panel_on_side = false;                                  // is the current panel k the product of stream2?
-    for (int64_t r0 = 0; r0 < pn; r0 += nb) {
-        const int64_t w = (pn - r0 < nb) ? (pn - r0) : nb;   // panel k (already factored)
+    bool panel_on_side = false;                                  // is the current super-panel the product of stream2?
+    for (int64_t r0 = 0; r0 < pn;) {
+        const int64_t w = wc;                                 // super-panel k (already factored)
         const int64_t t = pn - r0 - w;                        // trailing size
         if (t <= 0) break;
         const int64_t r1 = r0 + w;
-        const int64_t w1 = (pn - r1 < nb) ? (pn - r1) : nb;   // panel k+1
-        const double* P = A + r1 * lda + r0;                  // rows r1.., the w columns of panel k
+        const int64_t w1 = super_width(r1);                  // super-panel k+1
+        const double* P = A + r1 * lda + r0;                  // rows r1.., the w columns of super-panel k
         const int64_t t2 = t - w1;
         if (lookahead) {
-            // main stream: wait for panel k (before ev_panel is recorded again below)
+            // main stream: wait for super-panel k (before ev_panel is recorded again below)
             if (panel_on_side) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
             // second stream, enqueued first so that it gets the first free CUs:
-            //   A[r1:pn, r1:r1+w1] -= P P[0:w1]^T, then factor panel k+1
+            //   A[r1:pn, r1:r1+w1] -= P P[0:w1]^T, then factor super-panel k+1
             MGPI_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_upd, 0));
             ctx->stream = ctx->stream2;
             mgpi_prof_begin(ctx, 3);
             int rc = mgpi_launch_gemm(ctx, 0, 0, 0, t, w1, w, P, lda, P, lda, A + r1 * lda + r1, lda);
             mgpi_prof_end(ctx, 3);
-            if (rc == 0) {
-                ctx->lean = 1;
-                rc = factor_panel(r1, w1);
-                ctx->lean = 0;
-            }
+            if (rc == 0) rc = factor_super(r1, w1, true);
             ctx->stream = main_stream;
             MGPI_TRY(rc);
             MGPI_HIP_TRY(hipEventRecord(ctx->ev_panel, ctx->stream2));
@@ -363,6 +393,7 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
                 const double* P2 = P + w1 * lda;
                 MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 1, t2, t2, w, P2, lda, P2, lda, A + (r1 + w1) * lda + (r1 + w1), lda));
                 mgpi_prof_end(ctx, 0);
+                mgpi_prof_flops(ctx, 0, (double)t2 * ((double)t2 + 1.0) * (double)w);
             }
             MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
         } else {
@@ -370,15 +401,18 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
             MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, t, w1, w, P, lda, P, lda, A + r1 * lda + r1, lda));
             mgpi_prof_end(ctx, 3);
             mgpi_prof_begin(ctx, 1);
-            MGPI_TRY(factor_panel(r1, w1));
+            MGPI_TRY(factor_super(r1, w1, false));
             mgpi_prof_end(ctx, 1);
             if (t2 > 0) {
                 mgpi_prof_begin(ctx, 0);
                 const double* P2 = P + w1 * lda;
                 MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 1, t2, t2, w, P2, lda, P2, lda, A + (r1 + w1) * lda + (r1 + w1), lda));
                 mgpi_prof_end(ctx, 0);
+                mgpi_prof_flops(ctx, 0, (double)t2 * ((double)t2 + 1.0) * (double)w);
             }
         }
+        r0 = r1;
+        wc = w1;
     }
     if (lookahead && panel_on_side) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
 

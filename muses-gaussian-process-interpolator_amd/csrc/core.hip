@@ -204,6 +204,7 @@ extern "C" int mgpi_ctx_set_profile(mgpi_ctx* ctx, int on) {
         ctx->prof[s].used = 0;
         ctx->prof[s].ms = 0.0;
         ctx->prof[s].launches = 0;
+        ctx->prof[s].flops = 0.0;
     }
     return 0;
 }
@@ -224,6 +225,16 @@ extern "C" int mgpi_ctx_get_profile(mgpi_ctx* ctx, int which, double* ms, int64_
     if (ms) *ms = total;
     if (launches) *launches = p.launches;
     return 0;
+}
+
+extern "C" int mgpi_ctx_get_profile_flops(mgpi_ctx* ctx, int which, double* flops) {
+    MGPI_REQUIRE(ctx != nullptr && flops != nullptr && which >= 0 && which < 4, "mgpi_ctx_get_profile_flops: bad argument");
+    *flops = ctx->prof[which].flops;
+    return 0;
+}
+
+void mgpi_prof_flops(mgpi_ctx* ctx, int slot, double flops) {
+    if (ctx->profile) ctx->prof[slot].flops += flops;
 }
 
 // HIP-event pair around a launch (or a group of launches) on the ctx stream; nothing waits on the host

@@ -16,6 +16,7 @@ struct mgpi_prof_slot {
     size_t used;
     double ms;          // filled by mgpi_prof_collect
     int64_t launches;
+    double flops;       // algorithmic flops of the launches recorded in this slot (set by the launcher)
 };
 
 struct mgpi_pool;
@@ -124,3 +125,4 @@ int mgpi_launch_trsm_cols(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double*
 
 void mgpi_prof_begin(mgpi_ctx* ctx, int slot);
 void mgpi_prof_end(mgpi_ctx* ctx, int slot);
+void mgpi_prof_flops(mgpi_ctx* ctx, int slot, double flops);

@@ -191,11 +191,14 @@ def test_gemm_staircase_matches_block_cyclic_definition(ctx, P, p, Q, q, bi0, bj
 
 
 @pytest.mark.parametrize('env', [{'MGPI_GEMM_PIPE': '0'}, {'MGPI_GEMM_PIPE': '0', 'MGPI_GEMM_GLDS': '0'}, {'MGPI_GEMM_PP': '1'},
-                                 {'MGPI_NO_LOOKAHEAD': '1'}, {'MGPI_POOL_MB': '0'}, {'MGPI_HIP_RUNTIME': 'system'}, {}],
+                                 {'MGPI_NO_LOOKAHEAD': '1'}, {'MGPI_POOL_MB': '0'}, {'MGPI_HIP_RUNTIME': 'system'},
+                                 {'MGPI_SUPER_PANELS': '1', 'MGPI_SUPER_MIN': '512'}, {'MGPI_SUPER_PANELS': '2', 'MGPI_SUPER_MIN': '512'},
+                                 {'MGPI_SUPER_PANELS': '4', 'MGPI_SUPER_MIN': '512'}, {}],
                          ids=lambda e: ','.join('%s=%s' % kv for kv in e.items()) or 'defaults')
 def test_developer_switch_variants(env):
     """every kernel variant kept behind an environment switch (DESIGN.md section c) computes the same results:
-    the plain and register-staged 128x128 gemm, the ping-pong gemm, no look-ahead, no buffer pool, /opt/rocm's runtime"""
+    the plain and register-staged 128x128 gemm, the ping-pong gemm, no look-ahead, no buffer pool, /opt/rocm's runtime,
+    1 / 2 / 4 panels per trailing update (with a threshold small enough for the two-level schedule to engage)"""
     import os
     import subprocess
     import sys

@@ -7,7 +7,7 @@ import mgpi_amd as mgpi
 from mgpi_amd import _lib
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-k = 512
+k = int(sys.argv[3]) if len(sys.argv) > 3 else 512
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 ctx = mgpi.default_context()
 rng = np.random.default_rng(0)
