@@ -284,14 +284,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(int64_t k, const doubl
         compute_stage(lds + cur * STAGE, lds + cur * STAGE + GA::doubles);
     }
 
-    // epilogue: the accumulators hold C - A B
+    // epilogue: the accumulators hold C - A B.  The row pointers are rebuilt from a laundered thread id: kept live from
+    // the prologue they would hold 32 VGPRs across the K loop.
+    int tid2 = tid;
+    asm volatile("" : "+v"(tid2));
+    {
+        const int lane2 = tid2 & 63, wave2 = tid2 >> 6;
+        double* c0 = C + (m0 + (wave2 >> 1) * WM + (lane2 >> 4)) * ldc + n0 + (wave2 & 1) * WN + (lane2 & 15);
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+            for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                C[(m0 + wr * WM + i * 16 + fq + 4 * r) * ldc + n0 + wc * WN + j * 16 + fr] = acc[i][j][r];
+                for (int r = 0; r < 4; ++r) c0[(i * 16 + 4 * r) * ldc + j * 16] = acc[i][j][r];
+    }
 }
 
 // ---- software-pipelined 128x128 kernel (the shipped trailing-update kernel) --------------------------------------
