@@ -214,11 +214,14 @@ int mgpi_launch_trsm_rows(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double*
 // [16q, 16q+16) of the block).
 //   L x = b   : forward sweep,  C[k][m] = L[m][k], m > k
 //   L^T x = b : backward sweep, C[k][m] = L[k][m], m < k
+// blockIdx.y: one problem of a strided batch (sL / sB doubles apart; a 1-deep grid and zero strides otherwise)
 template <bool TRANS>
 __global__ __launch_bounds__(256) void trsm_cols_kernel(const double* __restrict__ Ljj, int64_t ldl,
-                                                        double* __restrict__ B, int64_t ldb) {
+                                                        double* __restrict__ B, int64_t ldb, int64_t sL, int64_t sB) {
     __shared__ __attribute__((aligned(16))) double C[IB][IB];
     const int tid = threadIdx.x, q = tid & 3;
+    Ljj += (int64_t)blockIdx.y * sL;
+    B += (int64_t)blockIdx.y * sB;
     if (TRANS) stage_coeff<false, false>(Ljj, ldl, C, tid);
     else stage_coeff<true, true>(Ljj, ldl, C, tid);
     double* col = B + (int64_t)blockIdx.x * 64 + (tid >> 2) + (int64_t)(16 * q) * ldb;   // n is a multiple of 64
@@ -235,10 +238,62 @@ int mgpi_launch_trsm_cols(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double*
     if (n == 0) return 0;
     MGPI_REQUIRE(n % 64 == 0, "trsm_cols: n=%lld is not a multiple of 64", (long long)n);
     dim3 grid((unsigned)(n / 64)), block(256);
-    if (trans) hipLaunchKernelGGL(trsm_cols_kernel<true>, grid, block, 0, ctx->stream, Ljj, ldl, B, ldb);
-    else hipLaunchKernelGGL(trsm_cols_kernel<false>, grid, block, 0, ctx->stream, Ljj, ldl, B, ldb);
+    if (trans) hipLaunchKernelGGL(trsm_cols_kernel<true>, grid, block, 0, ctx->stream, Ljj, ldl, B, ldb, (int64_t)0, (int64_t)0);
+    else hipLaunchKernelGGL(trsm_cols_kernel<false>, grid, block, 0, ctx->stream, Ljj, ldl, B, ldb, (int64_t)0, (int64_t)0);
     MGPI_HIP_TRY(hipGetLastError());
     return 0;
+}
+
+// ---- inverse diagonal blocks of the factor (variance path only) ------------------------------------------------
+// D_b = -(L_bb)^-1 for every nb x nb diagonal block of L, all blocks at once: start from -I and run the forward block
+// solve of trsm_blocked on each block, the 8 inner steps batched over the blocks (2 launches per step instead of
+// 2 per step per block).  With D the diagonal solve of the multi-rhs forward substitution, V_b <- L_bb^-1 V_b, is ONE
+// gemm instead of a chain of 8 x (64-row gemm + 64-row substitution kernel) - the chain is what the variance of a
+// medium-sized problem spends its time in (N = 8192: 9.6 ms, of which the gemm work is 5).
+// Error budget: the product with an explicit inverse is accurate to ~cond(L_bb) eps relative to |V_b|, and
+// cond(L_bb) <= sqrt(cond K); the variance is compared at 1e-8 of the prior variance, which
+// leaves five orders of room at cond K = 1e7.  The factorisation and the solves that produce alpha do NOT use it.
+__global__ void neg_identity_kernel(double* __restrict__ X, int64_t ld, int64_t pn, int64_t nb) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < pn) X[i * ld + (i % nb)] = -1.0;
+}
+
+static int ensure_dinv(mgpi_ctx* ctx, const mgpi_mat* Lc) {
+    mgpi_mat* Lm = const_cast<mgpi_mat*>(Lc);          // a cache on the factor, invisible to the caller
+    const int64_t nb = ctx->nb;
+    if (Lm->dinv != nullptr && Lm->dinv_nb == nb) return 0;
+    const int64_t pn = Lm->prows <= Lm->pcols ? Lm->prows : mgpi_roundup(Lm->rows, IB);
+    if (Lm->dinv) {
+        mgpi_pool_free(ctx, Lm->dinv, Lm->dinv_bytes);
+        Lm->dinv = nullptr;
+    }
+    const size_t bytes = (size_t)pn * (size_t)nb * sizeof(double);
+    MGPI_TRY(mgpi_pool_alloc(ctx, bytes, &Lm->dinv, &Lm->dinv_bytes));
+    double* X = Lm->dinv;
+    const double* L = Lm->d;
+    const int64_t lda = Lm->ld;
+    MGPI_HIP_TRY(hipMemsetAsync(X, 0, bytes, ctx->stream));
+    hipLaunchKernelGGL(neg_identity_kernel, dim3((unsigned)((pn + 255) / 256)), dim3(256), 0, ctx->stream, X, nb, pn, nb);
+    const int64_t nfull = pn / nb, wlast = pn - nfull * nb;          // full blocks, width of a narrower last one
+    for (int64_t c0 = 0; c0 < nb; c0 += IB) {
+        const int batch = (int)(nfull + (wlast > c0 ? 1 : 0));
+        if (batch == 0) break;
+        if (c0 > 0)   // X_b[c0:c0+64, :] -= L_bb[c0:c0+64, 0:c0] X_b[0:c0, :]
+            MGPI_TRY(mgpi_launch_gemm_nn_batched(ctx, IB, nb, c0, L + c0 * lda, lda, nb * (lda + 1), X, nb, nb * nb,
+                                                 X + c0 * nb, nb, nb * nb, batch));
+        hipLaunchKernelGGL(trsm_cols_kernel<false>, dim3((unsigned)(nb / 64), (unsigned)batch), dim3(256), 0, ctx->stream,
+                           L + c0 * lda + c0, lda, X + c0 * nb, nb, nb * (lda + 1), nb * nb);
+    }
+    MGPI_HIP_TRY(hipGetLastError());
+    Lm->dinv_nb = nb;
+    return 0;
+}
+
+// rows [0, w) of T (zeroed, ldt) := L_bb^-1 * B[r0:r0+w, :]  then copied back over those rows of B
+__global__ void copy_rows_kernel(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst, int64_t ldd, int64_t rows,
+                                 int64_t cols) {
+    const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2, r = blockIdx.y;
+    if (c < cols && r < rows) *reinterpret_cast<double2*>(dst + r * ldd + c) = *reinterpret_cast<const double2*>(src + r * lds_ + c);
 }
 
 // ---- small helpers ------------------------------------------------------------------------------------
@@ -275,6 +330,10 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
     MGPI_REQUIRE(K->pcols >= K->prows || K->pcols >= mgpi_roundup(K->rows, IB),
                  "mgpi_potrf_dev: matrix must be tile padded (allocate with cols > %d)", MGPI_MAX_D);
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    if (K->dinv) {                                   // inverse diagonal blocks of a previous factor
+        mgpi_pool_free(ctx, K->dinv, K->dinv_bytes);
+        K->dinv = nullptr;
+    }
     const int64_t n = K->rows;
     const int64_t pn = K->prows <= K->pcols ? K->prows : mgpi_roundup(n, IB);   // factored extent (multiple of 64)
     const int64_t lda = K->ld;
@@ -436,14 +495,34 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
 }
 
 // ---- multi-rhs triangular solves:  L X = B (trans = 0),  L^T X = B (trans = 1),  B is (n x m) wide ------
-static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ldb, int64_t ncols, int trans) {
+static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ldb, int64_t ncols, int trans, int use_inv = 0) {
     const int64_t pn = Lm->prows <= Lm->pcols ? Lm->prows : mgpi_roundup(Lm->rows, IB);
     const int64_t lda = Lm->ld, nb = ctx->nb;
     const double* L = Lm->d;
     const int64_t nc = mgpi_roundup(ncols, 64);
     if (!trans) {
+        // the variance path may replace the chain of a diagonal block solve by one gemm with the block's inverse
+        double* T = nullptr;
+        size_t tbytes = 0;
+        if (use_inv && pn > nb) {
+            MGPI_TRY(ensure_dinv(ctx, Lm));
+            MGPI_TRY(mgpi_pool_alloc(ctx, (size_t)nb * (size_t)nc * sizeof(double), &T, &tbytes));
+        }
         // rows [r0, r0+w) of B <- L_bb^-1 (rows of B): 64-wide inner blocks, left-looking inside the outer block
         auto solve_diag_block = [&](int64_t r0, int64_t w) -> int {
+            if (T != nullptr) {
+                // T = 0 - (-(L_bb)^-1) B_b, then back over B_b; full-size tiles whatever the stream
+                const int lean = ctx->lean;
+                ctx->lean = 0;
+                hipError_t e = hipMemsetAsync(T, 0, (size_t)w * (size_t)nc * sizeof(double), ctx->stream);
+                int rc = (e == hipSuccess) ? mgpi_launch_gemm(ctx, 0, 1, 0, w, nc, w, Lm->dinv + r0 * nb, nb, B + r0 * ldb, ldb, T, nc)
+                                           : MGPI_ERR_HIP;
+                ctx->lean = lean;
+                if (rc) return rc;
+                hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((nc / 2 + 255) / 256), (unsigned)w), dim3(256), 0, ctx->stream,
+                                   T, nc, B + r0 * ldb, ldb, w, nc);
+                return 0;
+            }
             for (int64_t c0 = r0; c0 < r0 + w; c0 += IB) {
                 const int64_t kk = c0 - r0;
                 if (kk > 0)   // B[c0:c0+64,:] -= L[c0:c0+64, r0:c0] * B[r0:c0,:]
@@ -497,6 +576,7 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
             }
         }
         if (lookahead && block_on_side) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
+        if (T != nullptr) mgpi_pool_free(ctx, T, tbytes);      // reuse is ordered on the main stream, which has just joined
     } else {
         const int64_t nblk = (pn + nb - 1) / nb;
         for (int64_t b = nblk - 1; b >= 0; --b) {
@@ -516,8 +596,9 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
     return 0;
 }
 
-int mgpi_trsm_raw(mgpi_ctx* ctx, const mgpi_mat* L, double* B, int64_t ldb, int64_t ncols, int trans) {
-    return trsm_blocked(ctx, L, B, ldb, ncols, trans);
+int mgpi_trsm_raw(mgpi_ctx* ctx, const mgpi_mat* L, double* B, int64_t ldb, int64_t ncols, int trans, int use_inv) {
+    static const int allow = getenv("MGPI_VAR_DINV") ? atoi(getenv("MGPI_VAR_DINV")) : 1;     // developer switch
+    return trsm_blocked(ctx, L, B, ldb, ncols, trans, use_inv && allow);
 }
 
 extern "C" int mgpi_trsm_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* B, int trans) {

@@ -133,6 +133,10 @@ static void pool_free(mgpi_ctx* ctx, void* ptr, size_t bytes) {
     pool->held += bytes;
 }
 
+// pooled scratch blocks for the other translation units (the inverse diagonal blocks of a factor, chol.hip)
+int mgpi_pool_alloc(mgpi_ctx* ctx, size_t bytes, double** out, size_t* got) { return pool_alloc(ctx, bytes, out, got); }
+void mgpi_pool_free(mgpi_ctx* ctx, void* ptr, size_t bytes) { pool_free(ctx, ptr, bytes); }
+
 extern "C" int mgpi_ctx_trim(mgpi_ctx* ctx) {
     MGPI_REQUIRE(ctx != nullptr, "mgpi_ctx_trim: null pointer");
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
@@ -313,6 +317,10 @@ extern "C" int mgpi_mat_alloc_wide(mgpi_ctx* ctx, int64_t rows, int64_t cols, mg
 
 extern "C" int mgpi_mat_free(mgpi_mat* m) {
     if (!m) return 0;
+    if (m->dinv) {
+        (void)hipSetDevice(m->ctx->device);
+        pool_free(m->ctx, m->dinv, m->dinv_bytes);
+    }
     if (m->owns && m->d) {
         (void)hipSetDevice(m->ctx->device);
         pool_free(m->ctx, m->d, m->alloc_bytes);

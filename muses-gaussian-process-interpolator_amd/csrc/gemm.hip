@@ -171,11 +171,17 @@ struct gemm_stair {
     int prefix[GEMM_STAIR_BANDS + 1];
 };
 
+// blockIdx.y selects one problem of a strided batch (operand y starts sA / sB / sC doubles after operand y - 1); the
+// single-problem launches pass a 1-deep grid and zero strides
 template <int BM, int BN, bool AK, bool BKM, bool LOWER, bool GLDS = false>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(int64_t k, const double* __restrict__ A, int64_t lda,
                                                           const double* __restrict__ B, int64_t ldb,
                                                           double* __restrict__ C, int64_t ldc, int tiles_m,
-                                                          int tiles_n, int64_t ntiles, gemm_stair st) {
+                                                          int tiles_n, int64_t ntiles, gemm_stair st, int64_t sA,
+                                                          int64_t sB, int64_t sC) {
+    A += (int64_t)blockIdx.y * sA;
+    B += (int64_t)blockIdx.y * sB;
+    C += (int64_t)blockIdx.y * sC;
     constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
     constexpr int FM = WM / 16, FN = WN / 16;   // MFMA tiles per wave
     using GA = TileGeom<BM, AK>;
@@ -571,7 +577,21 @@ static int launch_one(mgpi_ctx* ctx, int64_t m, int64_t n, int64_t k, const doub
     const int64_t ntiles = LOWER ? tm * (tm + 1) / 2 : (st.on ? (int64_t)st.prefix[st.nbands] : tm * tn);
     MGPI_REQUIRE(ntiles > 0 && ntiles < (int64_t)2147483647, "gemm: tile count %lld out of range", (long long)ntiles);
     hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, AK, BKM, LOWER, GLDS>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, k,
-                       A, lda, B, ldb, C, ldc, (int)tm, (int)tn, ntiles, st);
+                       A, lda, B, ldb, C, ldc, (int)tm, (int)tn, ntiles, st, (int64_t)0, (int64_t)0, (int64_t)0);
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// strided batch of  C_y (m x n) -= A_y (m x k, row-major) * B_y (k x n, row-major)  with 64 x 64 tiles: the shape of
+// the blocked inversion of the factor's diagonal blocks (chol.hip), where every problem is small and there are N / nb
+int mgpi_launch_gemm_nn_batched(mgpi_ctx* ctx, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, int64_t sA,
+                                const double* B, int64_t ldb, int64_t sB, double* C, int64_t ldc, int64_t sC, int batch) {
+    if (m == 0 || n == 0 || k == 0 || batch == 0) return 0;
+    MGPI_REQUIRE(m % 64 == 0 && n % 64 == 0 && k % GEMM_BK == 0 && batch > 0 && batch < 65536,
+                 "batched gemm: m=%lld n=%lld k=%lld batch=%d", (long long)m, (long long)n, (long long)k, batch);
+    const int64_t tm = m / 64, tn = n / 64, ntiles = tm * tn;
+    hipLaunchKernelGGL((gemm_f64_kernel<64, 64, false, true, false, false>), dim3((unsigned)ntiles, (unsigned)batch), dim3(256), 0,
+                       ctx->stream, k, A, lda, B, ldb, C, ldc, (int)tm, (int)tn, ntiles, no_stair(), sA, sB, sC);
     MGPI_HIP_TRY(hipGetLastError());
     return 0;
 }

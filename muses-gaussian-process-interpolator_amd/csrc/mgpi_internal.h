@@ -51,6 +51,9 @@ struct mgpi_mat {
     int owns;
     int factored;                 // set by potrf
     size_t alloc_bytes;           // owners: size of the device block (>= prows*pcols*8 when it came from the pool)
+    double* dinv;                 // -(L_bb)^-1 of the factor's nb x nb diagonal blocks, block b at rows [b nb, ..), ld = dinv_nb;
+    int64_t dinv_nb;              //   built on demand by the variance path (chol.hip), dropped when the matrix is refactored
+    size_t dinv_bytes;
 };
 
 struct mgpi_pool_block { void* ptr; size_t bytes; };
@@ -86,6 +89,8 @@ void mgpi_set_error(const char* fmt, ...);
 static inline int64_t mgpi_roundup(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 int mgpi_ensure_work(mgpi_ctx* ctx, size_t bytes);
+int mgpi_pool_alloc(mgpi_ctx* ctx, size_t bytes, double** out, size_t* got);
+void mgpi_pool_free(mgpi_ctx* ctx, void* ptr, size_t bytes);
 
 // ---- device-side kernel descriptor (passed by value as a kernel argument) -------------------
 struct mgpi_terms_dev {
@@ -122,6 +127,8 @@ int mgpi_launch_potf2(mgpi_ctx* ctx, double* A, int64_t lda, int64_t pivot_base,
 int mgpi_launch_trsm_rows(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double* A, int64_t lda, int64_t rows);
 // multi-rhs 64-row block solves on B (64 x n): trans=0: L_jj^-1 B, trans=1: L_jj^-T B
 int mgpi_launch_trsm_cols(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double* B, int64_t ldb, int64_t n, int trans);
+int mgpi_launch_gemm_nn_batched(mgpi_ctx* ctx, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, int64_t sA,
+                                const double* B, int64_t ldb, int64_t sB, double* C, int64_t ldc, int64_t sC, int batch);
 
 void mgpi_prof_begin(mgpi_ctx* ctx, int slot);
 void mgpi_prof_end(mgpi_ctx* ctx, int slot);

@@ -4,7 +4,7 @@
 //   condition cov : cov = K** - V^T V                                  (:148,:157,:199)
 #include "cov_device.h"
 
-int mgpi_trsm_raw(mgpi_ctx* ctx, const mgpi_mat* L, double* B, int64_t ldb, int64_t ncols, int trans);
+int mgpi_trsm_raw(mgpi_ctx* ctx, const mgpi_mat* L, double* B, int64_t ldb, int64_t ncols, int trans, int use_inv);
 
 #define PM_CHUNK 512   // sources staged per workgroup pass
 
@@ -168,7 +168,7 @@ extern "C" int mgpi_predict_var_dev(mgpi_ctx* ctx, const mgpi_mat* Xs, const mgp
         // V = K(x, xs_slab): rows = sources (padded rows written as 0), cols = queries
         MGPI_TRY(mgpi_launch_cov(ctx, t, X->d, X->ld, n, pn, Xs->d + q0 * Xs->ld, Xs->ld, mq, pq, 0, 0, 0, V, m_slab));
         // V <- L^-1 V
-        MGPI_TRY(mgpi_trsm_raw(ctx, L, V, m_slab, pq, 0));
+        MGPI_TRY(mgpi_trsm_raw(ctx, L, V, m_slab, pq, 0, 1));     // variance path: inverse diagonal blocks allowed (chol.hip)
         dim3 grid((unsigned)((mq + 63) / 64), (unsigned)rchunks);
         hipLaunchKernelGGL(colsq_kernel, grid, dim3(256), 0, ctx->stream, V, m_slab, pn, mq, partial);
         MGPI_HIP_TRY(hipGetLastError());
@@ -216,7 +216,7 @@ extern "C" int mgpi_condition_cov_dev(mgpi_ctx* ctx, const mgpi_mat* Xs, const m
     MGPI_TRY(mgpi_launch_cov(ctx, t, Xs->d, Xs->ld, m, pm, Xs->d, Xs->ld, m, pm, 1, 0, 0, cov->d, cov->ld));
     // V = L^-1 K(x, xs) (interpolators.py:157, transposed)
     MGPI_TRY(mgpi_launch_cov(ctx, t, X->d, X->ld, n, pn, Xs->d, Xs->ld, m, pm, 0, 0, 0, V, pm));
-    MGPI_TRY(mgpi_trsm_raw(ctx, L, V, pm, pm, 0));
+    MGPI_TRY(mgpi_trsm_raw(ctx, L, V, pm, pm, 0, 1));
     // cov -= V^T V      (interpolators.py:199)
     return mgpi_launch_gemm(ctx, 1, 1, 0, pm, pm, pn, V, pm, V, pm, cov->d, cov->ld);
 }
