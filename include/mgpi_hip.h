@@ -171,6 +171,11 @@ int  mgpi_gemm_nt_stair_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* B,
                             int bi0, int bj0, int nb);
 /* A <- A L^-T : panel trsm with a factored diagonal block L (w x w) on a block of rows A (m x w) */
 int  mgpi_trsm_right_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* A);
+/* out rows [j w, (j+1) w) := -(A[r0 + j row_step : + w, c0 + j col_step : + w])^-1 for `batch` lower-triangular w x w
+ * blocks at a constant stride (the diagonal blocks a rank owns in its local block-cyclic factor).  Used by the
+ * VARIANCE sweep only, where a diagonal-block solve then becomes one gemm (error budget: DESIGN.md); w % 64 == 0 */
+int  mgpi_trtri_neg_dev(mgpi_ctx* ctx, const mgpi_mat* A, int64_t r0, int64_t c0, int64_t row_step, int64_t col_step, int64_t w,
+                        int batch, mgpi_mat* out);
 /* single-vector half-solve with a factored diagonal block (<= 4096 rows): L y = b (trans=0) / L^T x = b (trans=1) */
 int  mgpi_trsv_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* v, int trans);
 /* y -= A x (trans=0) or y -= A^T x (trans=1); x, y vectors (ld == 1) */

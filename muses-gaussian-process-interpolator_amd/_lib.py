@@ -90,6 +90,7 @@ _SIGNATURES = {
     'mgpi_cov_block_dev': (ctypes.c_int, [_vp, _vp, c_int64, _vp, c_int64, ctypes.POINTER(KernelDesc), ctypes.c_int, _vp]),
     'mgpi_gemm_nn_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     'mgpi_gemm_nt_stair_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp] + [ctypes.c_int] * 7),
+    'mgpi_trtri_neg_dev': (ctypes.c_int, [_vp, _vp, c_int64, c_int64, c_int64, c_int64, c_int64, ctypes.c_int, _vp]),
     'mgpi_trsm_right_dev': (ctypes.c_int, [_vp, _vp, _vp]),
     'mgpi_trsv_dev': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
     'mgpi_gemv_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int]),

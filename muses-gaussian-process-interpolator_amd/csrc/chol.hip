@@ -253,9 +253,29 @@ int mgpi_launch_trsm_cols(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double*
 // Error budget: the product with an explicit inverse is accurate to ~cond(L_bb) eps relative to |V_b|, and
 // cond(L_bb) <= sqrt(cond K); the variance is compared at 1e-8 of the prior variance, which
 // leaves five orders of room at cond K = 1e7.  The factorisation and the solves that produce alpha do NOT use it.
-__global__ void neg_identity_kernel(double* __restrict__ X, int64_t ld, int64_t pn, int64_t nb) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < pn) X[i * ld + (i % nb)] = -1.0;
+__global__ void neg_identity_kernel(double* __restrict__ X, int64_t ldx, int64_t sX, int64_t w, int batch) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id < (int64_t)batch * w) {
+        const int64_t j = id / w, i = id % w;
+        X[j * sX + i * ldx + i] = -1.0;
+    }
+}
+
+// X_j (w x w, row stride ldx, sX doubles apart, ZEROED by the caller) := -(L_j)^-1 for `batch` lower-triangular blocks
+// L_j (row stride lda, sL doubles apart); w a multiple of 64
+static int invert_lower_blocks(mgpi_ctx* ctx, const double* L, int64_t lda, int64_t sL, double* X, int64_t ldx, int64_t sX,
+                               int64_t w, int batch) {
+    if (batch <= 0 || w <= 0) return 0;
+    MGPI_REQUIRE(w % IB == 0, "block inversion: width %lld is not a multiple of %d", (long long)w, IB);
+    hipLaunchKernelGGL(neg_identity_kernel, dim3((unsigned)((batch * w + 255) / 256)), dim3(256), 0, ctx->stream, X, ldx, sX, w, batch);
+    for (int64_t c0 = 0; c0 < w; c0 += IB) {
+        if (c0 > 0)   // X_j[c0:c0+64, :] -= L_j[c0:c0+64, 0:c0] X_j[0:c0, :]
+            MGPI_TRY(mgpi_launch_gemm_nn_batched(ctx, IB, w, c0, L + c0 * lda, lda, sL, X, ldx, sX, X + c0 * ldx, ldx, sX, batch));
+        hipLaunchKernelGGL(trsm_cols_kernel<false>, dim3((unsigned)(w / 64), (unsigned)batch), dim3(256), 0, ctx->stream,
+                           L + c0 * lda + c0, lda, X + c0 * ldx, ldx, sL, sX);
+    }
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 static int ensure_dinv(mgpi_ctx* ctx, const mgpi_mat* Lc) {
@@ -270,23 +290,32 @@ static int ensure_dinv(mgpi_ctx* ctx, const mgpi_mat* Lc) {
     const size_t bytes = (size_t)pn * (size_t)nb * sizeof(double);
     MGPI_TRY(mgpi_pool_alloc(ctx, bytes, &Lm->dinv, &Lm->dinv_bytes));
     double* X = Lm->dinv;
-    const double* L = Lm->d;
     const int64_t lda = Lm->ld;
     MGPI_HIP_TRY(hipMemsetAsync(X, 0, bytes, ctx->stream));
-    hipLaunchKernelGGL(neg_identity_kernel, dim3((unsigned)((pn + 255) / 256)), dim3(256), 0, ctx->stream, X, nb, pn, nb);
     const int64_t nfull = pn / nb, wlast = pn - nfull * nb;          // full blocks, width of a narrower last one
-    for (int64_t c0 = 0; c0 < nb; c0 += IB) {
-        const int batch = (int)(nfull + (wlast > c0 ? 1 : 0));
-        if (batch == 0) break;
-        if (c0 > 0)   // X_b[c0:c0+64, :] -= L_bb[c0:c0+64, 0:c0] X_b[0:c0, :]
-            MGPI_TRY(mgpi_launch_gemm_nn_batched(ctx, IB, nb, c0, L + c0 * lda, lda, nb * (lda + 1), X, nb, nb * nb,
-                                                 X + c0 * nb, nb, nb * nb, batch));
-        hipLaunchKernelGGL(trsm_cols_kernel<false>, dim3((unsigned)(nb / 64), (unsigned)batch), dim3(256), 0, ctx->stream,
-                           L + c0 * lda + c0, lda, X + c0 * nb, nb, nb * (lda + 1), nb * nb);
-    }
-    MGPI_HIP_TRY(hipGetLastError());
+    MGPI_TRY(invert_lower_blocks(ctx, Lm->d, lda, nb * (lda + 1), X, nb, nb * nb, nb, (int)nfull));
+    MGPI_TRY(invert_lower_blocks(ctx, Lm->d + nfull * nb * (lda + 1), lda, 0, X + nfull * nb * nb, nb, 0, wlast, wlast > 0 ? 1 : 0));
     Lm->dinv_nb = nb;
     return 0;
+}
+
+// Strided batch for the multi-GPU driver: block j is A[r0 + j row_step : + w, c0 + j col_step : + w] (the diagonal
+// blocks a rank owns sit at a constant stride in its local block-cyclic matrix); out rows [j w, (j+1) w) := -(block j)^-1.
+extern "C" int mgpi_trtri_neg_dev(mgpi_ctx* ctx, const mgpi_mat* A, int64_t r0, int64_t c0, int64_t row_step, int64_t col_step,
+                                  int64_t w, int batch, mgpi_mat* out) {
+    MGPI_REQUIRE(ctx && A && out, "mgpi_trtri_neg_dev: null pointer");
+    MGPI_REQUIRE(batch >= 1 && w >= IB && w % IB == 0, "mgpi_trtri_neg_dev: batch=%d, w=%lld (a positive multiple of %d)", batch,
+                 (long long)w, IB);
+    MGPI_REQUIRE(r0 >= 0 && c0 >= 0 && row_step >= 0 && col_step >= 0 && r0 + (batch - 1) * row_step + w <= A->prows &&
+                     c0 + (batch - 1) * col_step + w <= A->pcols,
+                 "mgpi_trtri_neg_dev: blocks reach outside the %lld x %lld matrix", (long long)A->prows, (long long)A->pcols);
+    MGPI_REQUIRE(out->prows >= (int64_t)batch * w && out->pcols >= w, "mgpi_trtri_neg_dev: out is %lld x %lld, needs %lld x %lld",
+                 (long long)out->prows, (long long)out->pcols, (long long)batch * w, (long long)w);
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    MGPI_HIP_TRY(hipMemset2DAsync(out->d, (size_t)out->ld * sizeof(double), 0, (size_t)w * sizeof(double), (size_t)batch * w,
+                                  ctx->stream));
+    out->factored = 0;
+    return invert_lower_blocks(ctx, A->d + r0 * A->ld + c0, A->ld, row_step * A->ld + col_step, out->d, out->ld, w * out->ld, w, batch);
 }
 
 // rows [0, w) of T (zeroed, ldt) := L_bb^-1 * B[r0:r0+w, :]  then copied back over those rows of B

@@ -248,6 +248,14 @@ class HipTileBackend(object):
         finally:
             self._free(hc, ha, hb)
 
+    def trtri_neg(self, a_local, r0, c0, row_step, col_step, w, batch, out):
+        """out rows [j w, (j+1) w) = -(a_local[r0 + j row_step : + w, c0 + j col_step : + w])^-1 (lower triangular blocks)"""
+        ha, ho = self._wrap(a_local), self._wrap(out)
+        try:
+            _lib.check(self.lib.mgpi_trtri_neg_dev(self.ctx.handle, ha, r0, c0, row_step, col_step, w, batch, ho))
+        finally:
+            self._free(ha, ho)
+
     def trsm_left(self, lkk, rhs):
         a, b = self._wrap(lkk, 1), self._wrap(rhs)
         try:
@@ -319,6 +327,7 @@ class DistributedGP(object):
         self.column_flops = 0.0     # ... and of its next-panel column updates on the look-ahead stream
         self.row_panels = None        # L[I][k] for the local block rows, every block step k (filled by factor)
         self._row_panel_offset = None
+        self._dinv = None             # {k: -(L_kk)^-1} for the diagonal blocks this rank owns (variance sweep only)
 
     # -- index helpers ------------------------------------------------------------------------------------
     def _global_index(self, blocks):
@@ -350,6 +359,7 @@ class DistributedGP(object):
     # -- build --------------------------------------------------------------------------------------------
     def build(self):
         be, nb = self.be, self.nb
+        self._dinv = None
         gi = self._global_index(self.row_blocks)
         gj = self._global_index(self.col_blocks)
         nvr = int(np.sum(gi < self.n))
@@ -460,6 +470,7 @@ class DistributedGP(object):
         issues the same collectives in the same order in both modes."""
         import os
         g, be, nb = self.g, self.be, self.nb
+        self._dinv = None
         if lookahead is None:
             lookahead = os.environ.get('MGPI_DIST_LOOKAHEAD', '1') != '0'
         side = be.side_backend() if lookahead else be
@@ -589,6 +600,23 @@ class DistributedGP(object):
         g.all_gather(parts, mine)
         return np.concatenate([be.to_numpy(t) for t in parts])[:m]
 
+    def _ensure_dinv(self):
+        """-(L_kk)^-1 of the diagonal blocks this rank owns, all in one batched call: they sit at a constant stride in
+        the local matrix (k = k0, k0 + lcm(P, Q), ..).  Variance sweep only (error budget: DESIGN.md)."""
+        if self._dinv is not None:
+            return
+        g, be, nb = self.g, self.be, self.nb
+        mine = [k for k in range(self.nblk) if k % g.P == g.p and k % g.Q == g.q]
+        self._dinv = {}
+        if not mine:
+            return
+        lcm = g.P * g.Q // math.gcd(g.P, g.Q)
+        assert all(b - a == lcm for a, b in zip(mine, mine[1:]))
+        out = be.empty(len(mine) * nb, nb)
+        be.trtri_neg(self.A, (mine[0] // g.P) * nb, (mine[0] // g.Q) * nb, (lcm // g.P) * nb, (lcm // g.Q) * nb, nb, len(mine), out)
+        for j, k in enumerate(mine):
+            self._dinv[k] = out[j * nb:(j + 1) * nb]
+
     def variance(self, target_x):
         """pointwise posterior variance: V = L^-1 K(x, x*) by the same block-cyclic sweep (queries sharded over
         process columns, rows of V distributed like the rows of L), then column norms"""
@@ -607,19 +635,33 @@ class DistributedGP(object):
         xq[:hi - lo] = xs[lo:hi]
         V = be.zeros(self.mloc, per)
         be.cov(xr, xq, self.kernel_terms, V, nvr, hi - lo)
+        import os
+        use_inv = os.environ.get('MGPI_DIST_VAR_DINV', '1') != '0'
+        if use_inv:
+            self._ensure_dinv()
         for k in range(self.nblk):
             pk, qk = k % g.P, k % g.Q
             kr, kc = k // g.P, k // g.Q
             i0 = self._first_local(self.row_blocks, k)
             mt = self.mloc - i0 * nb
-            # diagonal block to the whole process row pk, which solves its slice of block row k of V
+            # diagonal block to the whole process row pk, which solves its slice of block row k of V.  With the
+            # inverse diagonal blocks (default) what travels is -(L_kk)^-1 and the solve is one gemm instead of the
+            # 8-step substitution chain, which would otherwise sit on the critical path of every block step
             vk = be.empty(nb, per)
             if g.p == pk:
                 lkk = be.empty(nb, nb)
-                if g.q == qk:
-                    lkk.copy_(A[kr * nb:(kr + 1) * nb, kc * nb:(kc + 1) * nb])
-                self._bcast_row(lkk, pk, qk)
-                be.trsm_left(lkk, V[kr * nb:(kr + 1) * nb])
+                if use_inv:
+                    if g.q == qk:
+                        lkk.copy_(self._dinv[k])
+                    self._bcast_row(lkk, pk, qk)
+                    solved = be.zeros(nb, per)
+                    be.gemm_nn(solved, lkk, V[kr * nb:(kr + 1) * nb])            # 0 - (-(L_kk)^-1) V_k
+                    V[kr * nb:(kr + 1) * nb].copy_(solved)
+                else:
+                    if g.q == qk:
+                        lkk.copy_(A[kr * nb:(kr + 1) * nb, kc * nb:(kc + 1) * nb])
+                    self._bcast_row(lkk, pk, qk)
+                    be.trsm_left(lkk, V[kr * nb:(kr + 1) * nb])
                 vk.copy_(V[kr * nb:(kr + 1) * nb])
             self._bcast_col(vk, g.q, pk)
             # panel blocks L[I][k], I > k: every rank kept its row panel of step k from the factorisation

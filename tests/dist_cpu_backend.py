@@ -82,6 +82,13 @@ class NumpyTileBackend(object):
     def gemm_nn(self, c, a, b):
         c.numpy()[:] -= a.numpy() @ b.numpy()
 
+    def trtri_neg(self, a_local, r0, c0, row_step, col_step, w, batch, out):
+        a, o = a_local.numpy(), out.numpy()
+        o[:batch * w, :w] = 0.0
+        for j in range(batch):
+            blk = np.tril(a[r0 + j * row_step:r0 + j * row_step + w, c0 + j * col_step:c0 + j * col_step + w])
+            o[j * w:(j + 1) * w, :w] = -solve_triangular(blk, np.eye(w), lower=True)
+
     def trsm_left(self, lkk, rhs):
         r = rhs.numpy()
         r[:] = solve_triangular(np.tril(lkk.numpy()), r, lower=True)
