@@ -190,10 +190,35 @@ def test_gemm_staircase_matches_block_cyclic_definition(ctx, P, p, Q, q, bi0, bj
     assert np.array_equal(got[~live], C[~live])
 
 
+@pytest.mark.parametrize('w,batch,row_step,col_step', [(64, 1, 0, 0), (128, 3, 256, 128), (512, 2, 512, 1024), (256, 5, 256, 256)])
+def test_trtri_neg_strided_batch(ctx, w, batch, row_step, col_step):
+    """-(block)^-1 for lower-triangular blocks at a constant stride (the diagonal blocks a rank owns in a block-cyclic
+    factor): against numpy, and the strict upper triangle of the result is exactly zero"""
+    rng = np.random.default_rng(w + batch)
+    r0, c0 = 64, 128
+    rows, cols = r0 + (batch - 1) * row_step + w, c0 + (batch - 1) * col_step + w
+    A = rng.standard_normal((rows, cols))
+    for j in range(batch):
+        blk = np.tril(rng.standard_normal((w, w))) * 0.1 + np.diag(1.0 + rng.random(w))
+        A[r0 + j * row_step:r0 + j * row_step + w, c0 + j * col_step:c0 + j * col_step + w] = blk + np.triu(rng.standard_normal((w, w)), 1)
+    dA = dev(ctx, A)
+    out = _lib.DeviceMatrix(ctx, batch * w, w, wide=True)
+    _lib.check(ctx.lib.mgpi_trtri_neg_dev(ctx.handle, dA.handle, r0, c0, row_step, col_step, w, batch, out.handle))
+    got = out.to_host()
+    for j in range(batch):
+        blk = np.tril(A[r0 + j * row_step:r0 + j * row_step + w, c0 + j * col_step:c0 + j * col_step + w])
+        want = -np.linalg.inv(blk)
+        g = got[j * w:(j + 1) * w]
+        assert np.max(np.abs(g - want)) < 1e-12 * np.max(np.abs(want))
+        assert np.count_nonzero(np.triu(g, 1)) == 0
+    with pytest.raises(mgpi.MgpiError):
+        _lib.check(ctx.lib.mgpi_trtri_neg_dev(ctx.handle, dA.handle, r0, c0, row_step, col_step, w, batch + 50, out.handle))
+
+
 @pytest.mark.parametrize('env', [{'MGPI_GEMM_PIPE': '0'}, {'MGPI_GEMM_PIPE': '0', 'MGPI_GEMM_GLDS': '0'}, {'MGPI_GEMM_PP': '1'},
                                  {'MGPI_NO_LOOKAHEAD': '1'}, {'MGPI_POOL_MB': '0'}, {'MGPI_HIP_RUNTIME': 'system'},
                                  {'MGPI_SUPER_PANELS': '1', 'MGPI_SUPER_MIN': '512'}, {'MGPI_SUPER_PANELS': '2', 'MGPI_SUPER_MIN': '512'},
-                                 {'MGPI_SUPER_PANELS': '4', 'MGPI_SUPER_MIN': '512'}, {}],
+                                 {'MGPI_SUPER_PANELS': '4', 'MGPI_SUPER_MIN': '512'}, {'MGPI_VAR_DINV': '0'}, {}],
                          ids=lambda e: ','.join('%s=%s' % kv for kv in e.items()) or 'defaults')
 def test_developer_switch_variants(env):
     """every kernel variant kept behind an environment switch (DESIGN.md section c) computes the same results:
