@@ -11,6 +11,11 @@
 #include <math.h>
 #include <vector>
 
+// The latency-bound kernels of the panel chain share their SIMDs with two waves of the trailing update during the
+// look-ahead.  Their own instruction streams are short dependent chains; raising the wave priority lets the SIMD's
+// arbiter issue them as soon as they are ready instead of round-robin behind MFMA issues.
+#define MGPI_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
+
 #define IB MGPI_IB
 
 // ---- 64x64 diagonal block: unblocked Cholesky in LDS, one workgroup ------------------------------------
@@ -81,6 +86,7 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int6
                                                     const double* __restrict__ diag0, int* __restrict__ info) {
     __shared__ __attribute__((aligned(16))) double col[2][IB];
     __shared__ double dtol[IB];
+    MGPI_CHAIN_PRIO();
     const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
     double* row = A + (int64_t)r * lda + 16 * q;
     double a[16];
@@ -185,6 +191,7 @@ __device__ __forceinline__ void stage_coeff(const double* __restrict__ Ljj, int6
 __global__ __launch_bounds__(256) void trsm_rows_kernel(const double* __restrict__ Ljj, int64_t ldl,
                                                         double* __restrict__ A, int64_t lda) {
     __shared__ __attribute__((aligned(16))) double C[IB][IB];
+    MGPI_CHAIN_PRIO();
     const int tid = threadIdx.x, q = tid & 3;
     stage_coeff<true, true>(Ljj, ldl, C, tid);
     double* row = A + ((int64_t)blockIdx.x * IB + (tid >> 2)) * lda + 16 * q;
@@ -219,6 +226,7 @@ template <bool TRANS>
 __global__ __launch_bounds__(256) void trsm_cols_kernel(const double* __restrict__ Ljj, int64_t ldl,
                                                         double* __restrict__ B, int64_t ldb, int64_t sL, int64_t sB) {
     __shared__ __attribute__((aligned(16))) double C[IB][IB];
+    MGPI_CHAIN_PRIO();
     const int tid = threadIdx.x, q = tid & 3;
     Ljj += (int64_t)blockIdx.y * sL;
     B += (int64_t)blockIdx.y * sB;

@@ -182,6 +182,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(int64_t k, const doubl
     A += (int64_t)blockIdx.y * sA;
     B += (int64_t)blockIdx.y * sB;
     C += (int64_t)blockIdx.y * sC;
+    // the 64 x 64 form is the panel's gemm: during the look-ahead it shares its SIMDs with two trailing-update waves and
+    // sits on the chain the next big update waits for - let the arbiter issue it first (see chol.hip, MGPI_CHAIN_PRIO)
+    if constexpr (BM == 64 && BN == 64) __builtin_amdgcn_s_setprio(3);
     constexpr int WM = BM / 2, WN = BN / 2;     // wave tile
     constexpr int FM = WM / 16, FN = WN / 16;   // MFMA tiles per wave
     using GA = TileGeom<BM, AK>;
