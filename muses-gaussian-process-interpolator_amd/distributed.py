@@ -22,6 +22,7 @@ or column (backward) and one world broadcast of the nb solved entries.
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 
@@ -468,7 +469,6 @@ class DistributedGP(object):
         solve and all its broadcasts - run on a second stream while the rest of the trailing update of step k runs on
         the main stream, so the xGMI transfers and the latency-bound panel hide behind the MFMA work.  Every rank
         issues the same collectives in the same order in both modes."""
-        import os
         g, be, nb = self.g, self.be, self.nb
         self._dinv = None
         if lookahead is None:
@@ -635,7 +635,6 @@ class DistributedGP(object):
         xq[:hi - lo] = xs[lo:hi]
         V = be.zeros(self.mloc, per)
         be.cov(xr, xq, self.kernel_terms, V, nvr, hi - lo)
-        import os
         use_inv = os.environ.get('MGPI_DIST_VAR_DINV', '1') != '0'
         if use_inv:
             self._ensure_dinv()
