@@ -33,6 +33,15 @@ from .kernel_objects import Kernel
 __all__ = ['Interpolator', 'FittedGP']
 
 
+def _points(a):
+    """(P, D) float64 coordinates; an empty set raises IndexError like the reference (its pair builder reads row 0
+    first, interpolators.py:247-249)"""
+    a = _lib.as_f64(a, ndim=2)
+    if len(a) == 0:
+        raise IndexError('index 0 is out of bounds for axis 0 with size 0')
+    return a
+
+
 def _flatten(kernel, nugget=None):
     """ordered summands of kernel (+ nugget): what ``kernel+nugget`` means at interpolators.py:84,169,337"""
     terms = list(kernel.terms())
@@ -67,7 +76,7 @@ class FittedGP(object):
     def __init__(self, ctx, source_x, kernel_terms, solve_terms, stage=None):
         self.ctx = ctx
         self.lib = ctx.lib
-        x = _lib.as_f64(source_x, ndim=2)
+        x = _points(source_x)
         self.n, self.d = x.shape
         self.kernel_terms = list(kernel_terms)     # K*, K** : kernel only
         self.solve_terms = list(solve_terms)       # K       : kernel + nugget
@@ -105,7 +114,7 @@ class FittedGP(object):
         self.alpha = _lib.DeviceMatrix.from_host(self.ctx, a)
 
     def _targets(self, target_x):
-        xs = _lib.as_f64(target_x, ndim=2)
+        xs = _points(target_x)
         assert xs.shape[1] == self.d, 'conflicting number of dimensions for x1 and x2'   # interpolators.py:219
         return _lib.DeviceMatrix.from_host(self.ctx, xs)
 
@@ -194,8 +203,8 @@ class Interpolator(HyperParameterSearch):
         verbose |= Verbose
         ctx = self.context
         stage = _Stage(ctx, verbose)
-        xs = _lib.as_f64(target_x, ndim=2)
-        x = _lib.as_f64(source_x, ndim=2)
+        xs = _points(target_x)
+        x = _points(source_x)
         assert xs.shape[1] == x.shape[1], 'conflicting number of dimensions for x1 and x2'
         a = _lib.as_f64(compressed).reshape(-1)
         assert len(a) == len(x), 'compressed has %d entries for %d source points' % (len(a), len(x))
@@ -248,8 +257,8 @@ class Interpolator(HyperParameterSearch):
     @staticmethod
     def _x2cov(x1, x2, kernel, verbose=False):
         """K[i, j] = kernel.cov(x1[i], x2[j])  ->  (n1, n2)"""
-        a = _lib.as_f64(x1, ndim=2)
-        b = _lib.as_f64(x2, ndim=2)
+        a = _points(x1)
+        b = _points(x2)
         assert b.shape[1] == a.shape[1], 'conflicting number of dimensions for x1 and x2'
         ctx = _lib.default_context()
         desc, count = _lib.make_terms(kernel.terms())

@@ -195,6 +195,21 @@ def test_input_layouts_and_errors():
         bad.compress(xC, f)
 
 
+def test_empty_inputs_raise_like_the_reference():
+    """the reference's pair builder indexes row 0 before anything else (interpolators.py:247-249): every entry point
+    raises IndexError on an empty source or target set [measured on the reference]"""
+    it = mgpi.Interpolator(mgpi.SquaredExponentialKernel(1.0, 0.3, 0.3), nugget=mgpi.WhiteNoiseKernel(1e-2))
+    rng = np.random.default_rng(0)
+    x, f = rng.random((5, 2)), rng.random(5)
+    none_x, none_f = np.zeros((0, 2)), np.zeros(0)
+    for call in [lambda: it.condition(none_x, x, f), lambda: it.condition_diag(none_x, x, f),
+                 lambda: it.predict(none_x, x, it.compress(x, f)), lambda: it.condition(x, none_x, none_f),
+                 lambda: it.compress(none_x, none_f), lambda: it.loglikelihood(none_x, none_f),
+                 lambda: mgpi.Interpolator._x2cov(none_x, x, it.kernel), lambda: mgpi.Interpolator._x2cov(x, none_x, it.kernel)]:
+        with pytest.raises(IndexError):
+            call()
+
+
 def test_verbose_stage_banners(capsys):
     rng = np.random.default_rng(4)
     x = rng.random((20, 2))
