@@ -51,9 +51,16 @@ struct potf2_steps {
         const double d = col[K & 1][K];
         const bool ok = d > dtol[K];                                // false for NaN too
         if (!ok && bad == 0) bad = K + 1;
-        // 1/sqrt(pivot): hardware estimate + two Newton steps (a dependent fp64 op costs 32 cycles, so this
-        // chain, not the arithmetic volume, sets the time of the kernel)
+        // Two reciprocals of the pivot, deliberately separate.  A dependent fp64 op costs 32 cycles, so what sets the time
+        // of this kernel is the chain pivot -> multiplier -> update -> next pivot, not the arithmetic volume:
+        //  * ON the chain, the multiplier a_r[k] / pivot uses 1/pivot from v_rcp_f64 + ONE fma-form Newton step
+        //    (estimate ~2^-27 -> ~2^-53: two dependent ops);
+        //  * OFF the chain, 1/sqrt(pivot) (estimate + two Newton steps, eight dependent ops) only feeds the values that
+        //    are STORED as the factor - nothing later in the chain reads them - so it runs in the shadow of the update.
+        // (The first version derived the multiplier from 1/sqrt(pivot) squared and had all ten ops on the chain.)
         const double dd = ok ? d : 1.0;
+        double p = __builtin_amdgcn_rcp(dd);
+        p = fma(p, fma(-dd, p, 1.0), p);
         double y = __builtin_amdgcn_rsq(dd);
         y = fma(y * 0.5, fma(-dd * y, y, 1.0), y);
         y = fma(y * 0.5, fma(-dd * y, y, 1.0), y);
@@ -65,7 +72,7 @@ struct potf2_steps {
             c[j + 1] = v.y;
         }
         const double raw = potf2_quad_bcast<QK>(a[KL]);             // this row's entry of column k
-        const double t = (r > K) ? raw * (y * y) : 0.0;             // a_r[k] / pivot; rows <= k are finished
+        const double t = (r > K) ? raw * p : 0.0;                   // a_r[k] / pivot; rows <= k are finished
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[j] = fma(-t, c[j], a[j]);
         // the owning part stores the factor entry: sqrt(pivot) on the diagonal, a_r[k]/sqrt(pivot) below, 0 above
