@@ -7,7 +7,7 @@ import mgpi_amd as mgpi
 from bench import make_inputs
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-side = {65536: (16, 16, 16, 16), 49152: (16, 16, 16, 12), 32768: (32, 32, 32)}[n]
+side = {65536: (16, 16, 16, 16), 52224: (32, 34, 48), 49152: (16, 16, 16, 12), 40960: (32, 32, 40), 32768: (32, 32, 32)}[n]
 x, f, xs, ell = make_inputs(side, 4096, 3)
 it = mgpi.Interpolator(mgpi.SquaredExponentialKernel(1.0, *ell), nugget=mgpi.WhiteNoiseKernel(1e-2))
 ctx = it.context
