@@ -406,14 +406,25 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
 
     // panel factorisation of columns [r0, r0+w), rows [r0, pn): left-looking over 64-wide inner blocks; enqueued on
     // whatever ctx->stream currently is
+    // Right-looking inside the panel: after 64 columns are solved, ALL remaining columns of the panel are updated with
+    // them (contraction 64: four short stages, one launch) instead of updating the next 64 columns with everything
+    // solved so far (contraction up to 448: 28 stages, each waiting for its loads) right before they are factored.
+    // The gemm sits on the panel chain, so its latency is what counts: C2 potrf 10.6 -> 9.5 ms.  The panel's columns are
+    // written up to 7 times instead of once (<= 0.5 GB per panel at N = 32768), which the chain does not notice.
+    // MGPI_PANEL_RIGHT=0 restores the left-looking order (developer switch, tested).
+    static const bool panel_right = getenv("MGPI_PANEL_RIGHT") ? atoi(getenv("MGPI_PANEL_RIGHT")) != 0 : true;
     auto factor_panel = [&](int64_t r0, int64_t w) -> int {
         for (int64_t c0 = r0; c0 < r0 + w; c0 += IB) {
             const int64_t kk = c0 - r0;
-            if (kk > 0)   // A[c0:pn, c0:c0+64] -= A[c0:pn, r0:c0] * A[c0:c0+64, r0:c0]^T
+            if (kk > 0 && !panel_right)   // A[c0:pn, c0:c0+64] -= A[c0:pn, r0:c0] * A[c0:c0+64, r0:c0]^T
                 MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, pn - c0, IB, kk, A + c0 * lda + r0, lda, A + c0 * lda + r0, lda,
                                           A + c0 * lda + c0, lda));
             MGPI_TRY(mgpi_launch_potf2(ctx, A + c0 * lda + c0, lda, c0, ctx->d_diag + c0));
             MGPI_TRY(mgpi_launch_trsm_rows(ctx, A + c0 * lda + c0, lda, A + (c0 + IB) * lda + c0, lda, pn - c0 - IB));
+            const int64_t c1 = c0 + IB, rest = r0 + w - c1;
+            if (panel_right && rest > 0)  // A[c1:pn, c1:r0+w] -= A[c1:pn, c0:c1] * A[c1:r0+w, c0:c1]^T
+                MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, pn - c1, rest, IB, A + c1 * lda + c0, lda, A + c1 * lda + c0, lda,
+                                          A + c1 * lda + c1, lda));
         }
         return 0;
     };
