@@ -283,11 +283,13 @@ static int invert_lower_blocks(mgpi_ctx* ctx, const double* L, int64_t lda, int6
     if (batch <= 0 || w <= 0) return 0;
     MGPI_REQUIRE(w % IB == 0, "block inversion: width %lld is not a multiple of %d", (long long)w, IB);
     hipLaunchKernelGGL(neg_identity_kernel, dim3((unsigned)((batch * w + 255) / 256)), dim3(256), 0, ctx->stream, X, ldx, sX, w, batch);
-    for (int64_t c0 = 0; c0 < w; c0 += IB) {
-        if (c0 > 0)   // X_j[c0:c0+64, :] -= L_j[c0:c0+64, 0:c0] X_j[0:c0, :]
-            MGPI_TRY(mgpi_launch_gemm_nn_batched(ctx, IB, w, c0, L + c0 * lda, lda, sL, X, ldx, sX, X + c0 * ldx, ldx, sX, batch));
+    for (int64_t c0 = 0; c0 < w; c0 += IB) {       // right-looking: the batched gemm has a contraction of 64
         hipLaunchKernelGGL(trsm_cols_kernel<false>, dim3((unsigned)(w / 64), (unsigned)batch), dim3(256), 0, ctx->stream,
                            L + c0 * lda + c0, lda, X + c0 * ldx, ldx, sL, sX);
+        const int64_t c1 = c0 + IB;
+        if (c1 < w)   // X_j[c1:w, :] -= L_j[c1:w, c0:c1] X_j[c0:c1, :]
+            MGPI_TRY(mgpi_launch_gemm_nn_batched(ctx, w - c1, w, IB, L + c1 * lda + c0, lda, sL, X + c0 * ldx, ldx, sX,
+                                                 X + c1 * ldx, ldx, sX, batch));
     }
     MGPI_HIP_TRY(hipGetLastError());
     return 0;
@@ -1062,10 +1064,13 @@ extern "C" int mgpi_trsm_right_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* A
     MGPI_REQUIRE(L->rows % IB == 0 && A->prows % IB == 0, "mgpi_trsm_right_dev: dimensions must be multiples of %d", IB);
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
     const int64_t w = L->rows, m = A->prows;
+    // right-looking over the 64-column blocks, like the panel of the factorisation: the gemm on the chain has a
+    // contraction of 64 instead of up to w - 64
     for (int64_t c0 = 0; c0 < w; c0 += IB) {
-        if (c0 > 0)   // A[:, c0:c0+64] -= A[:, 0:c0] * L[c0:c0+64, 0:c0]^T
-            MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, m, IB, c0, A->d, A->ld, L->d + c0 * L->ld, L->ld, A->d + c0, A->ld));
         MGPI_TRY(mgpi_launch_trsm_rows(ctx, L->d + c0 * L->ld + c0, L->ld, A->d + c0, A->ld, m));
+        const int64_t c1 = c0 + IB;
+        if (c1 < w)   // A[:, c1:w] -= A[:, c0:c1] * L[c1:w, c0:c1]^T
+            MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, m, w - c1, IB, A->d + c0, A->ld, L->d + c1 * L->ld + c0, L->ld, A->d + c1, A->ld));
     }
     return 0;
 }
