@@ -223,6 +223,94 @@ int mgpi_launch_trsm_rows(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double*
     return 0;
 }
 
+// potf2 + panel trsm in ONE launch: every workgroup factors the 64 x 64 diagonal block itself (the same arithmetic in
+// the same order, so all copies are identical), workgroup 0 stores it and reports a failed pivot, workgroup b >= 1
+// solves row block b - 1 below it against the factor it holds in registers - the coefficient image is written to LDS
+// straight from those registers, and the rows to solve are fetched before the factorisation starts, so their load
+// latency hides behind it.  One kernel boundary less on the panel chain (potf2 26 us + trsm 22 us stand-alone).
+__global__ __launch_bounds__(256) void potf2_trsm_kernel(double* __restrict__ A, int64_t lda, int64_t pivot_base,
+                                                         const double* __restrict__ diag0, int* __restrict__ info,
+                                                         double* __restrict__ S) {
+    __shared__ __attribute__((aligned(16))) double col[2][IB];
+    __shared__ double dtol[IB];
+    __shared__ __attribute__((aligned(16))) double C[IB][IB];
+    MGPI_CHAIN_PRIO();
+    const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
+    const double* drow = A + (int64_t)r * lda + 16 * q;
+    double a[16];
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(drow + j);
+        a[j] = (16 * q + j <= r) ? v.x : 0.0;           // only the lower triangle is read
+        a[j + 1] = (16 * q + j + 1 <= r) ? v.y : 0.0;
+    }
+    if (q == 0) dtol[r] = MGPI_PIVOT_TOL * fabs(diag0[r]);
+    double* xrow = A + ((int64_t)blockIdx.x * IB + r) * lda + 16 * q;     // workgroup b: rows [64 b, 64 b + 64) below the block's top
+    double x[16];
+    if (blockIdx.x > 0) {
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(xrow + j);
+            x[j] = v.x;
+            x[j + 1] = v.y;
+        }
+    }
+    int bad = 0;
+    potf2_steps<0>::run(a, col, dtol, r, q, bad);
+    if (blockIdx.x == 0) {
+        // NOT in place: the other workgroups of this launch may not have read the unfactored block yet (with 512 of them
+        // and a busy chip some start long after this one is done).  The factor goes to the scratch strip S (64 wide) and
+        // is copied over the diagonal blocks when the whole factorisation is done (diag_blocks_back_kernel); nothing in
+        // between reads a diagonal block that has been factored.
+        double* row = S + (int64_t)r * IB + 16 * q;
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            const double2 v = make_double2((16 * q + j <= r) ? a[j] : 0.0, (16 * q + j + 1 <= r) ? a[j + 1] : 0.0);
+            *reinterpret_cast<double2*>(row + j) = v;
+        }
+        if (tid == 0 && bad != 0) {
+            const int cand = (int)(pivot_base + bad);
+            int old = atomicCAS(info, 0, cand);
+            while (old != 0 && old > cand) {
+                const int prev = atomicCAS(info, old, cand);
+                if (prev == old) break;
+                old = prev;
+            }
+        }
+        return;
+    }
+    // coefficient image of the forward sweep X L^T = A:  C[k][m] = L[m][k] (m > k), 1 / L[k][k] (m == k), 0 (m < k);
+    // this thread holds L[r][16 q + j]
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int k = 16 * q + j;
+        C[k][r] = (k < r) ? a[j] : ((k == r) ? 1.0 / a[j] : 0.0);
+    }
+    __syncthreads();
+    quad_sweep<IB - 1, true>::run(x, C, q);
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) *reinterpret_cast<double2*>(xrow + j) = make_double2(x[j], x[j + 1]);
+}
+
+// A[64 k + i][64 k + j] = S[64 k + i][j]: the factored diagonal blocks back into the matrix
+__global__ __launch_bounds__(256) void diag_blocks_back_kernel(double* __restrict__ A, int64_t lda, const double* __restrict__ S,
+                                                               int64_t first) {
+    const int64_t k = first + blockIdx.x;
+    for (int idx = threadIdx.x; idx < IB * IB; idx += 256) {
+        const int i = idx >> 6, j = idx & 63;
+        A[(k * IB + i) * lda + k * IB + j] = S[(k * IB + i) * IB + j];
+    }
+}
+
+// the diagonal block at A, `rows` rows below it (a multiple of 64, may be 0); S: where the factored block goes
+int mgpi_launch_potf2_trsm(mgpi_ctx* ctx, double* A, int64_t lda, int64_t pivot_base, const double* diag0, int64_t rows, double* S) {
+    MGPI_REQUIRE(rows % IB == 0, "potf2_trsm: rows=%lld not a multiple of %d", (long long)rows, IB);
+    hipLaunchKernelGGL(potf2_trsm_kernel, dim3((unsigned)(1 + rows / IB)), dim3(256), 0, ctx->stream, A, lda, pivot_base, diag0,
+                       ctx->d_info, S);
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // multi-rhs 64-row block solve:  B <- L_jj^-1 B  (TRANS = false)  or  L_jj^-T B  (TRANS = true).
 // B is (64 x n) row-major; one 256-thread workgroup = 64 columns of B, 4 lanes per column (part q owns rows
 // [16q, 16q+16) of the block).
@@ -398,7 +486,8 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
             ctx->d_diag = nullptr;
             ctx->diag_len = 0;
         }
-        MGPI_HIP_TRY(hipMalloc((void**)&ctx->d_diag, (size_t)pn * sizeof(double)));
+        // diag(K) before factoring, then a 64-wide strip for the factored diagonal blocks (potf2_trsm_kernel)
+        MGPI_HIP_TRY(hipMalloc((void**)&ctx->d_diag, (size_t)pn * (1 + IB) * sizeof(double)));
         ctx->diag_len = pn;
     }
     hipLaunchKernelGGL(save_diag_kernel, dim3((unsigned)((pn + 255) / 256)), dim3(256), 0, ctx->stream, A, lda, pn,
@@ -415,14 +504,25 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
     // written up to 7 times instead of once (<= 0.5 GB per panel at N = 32768), which the chain does not notice.
     // MGPI_PANEL_RIGHT=0 restores the left-looking order (developer switch, tested).
     static const bool panel_right = getenv("MGPI_PANEL_RIGHT") ? atoi(getenv("MGPI_PANEL_RIGHT")) != 0 : true;
+    // potf2 and the panel trsm in one launch (potf2_trsm_kernel) while at most MGPI_PANEL_FUSE_ROWS rows lie below the
+    // diagonal block: every workgroup of the fused kernel repeats the 64 x 64 factorisation, which shortens the chain
+    // when the chip has room (C2 potrf 9.6 -> 8.7 ms) but costs CU time the trailing update wants when hundreds of them
+    // run beside it (C3 with fusion everywhere: potrf 188 -> 192 ms).  MGPI_PANEL_FUSE=0 keeps them apart.
+    static const bool panel_fused = getenv("MGPI_PANEL_FUSE") ? atoi(getenv("MGPI_PANEL_FUSE")) != 0 : true;
+    static const int64_t fuse_rows = getenv("MGPI_PANEL_FUSE_ROWS") ? atoll(getenv("MGPI_PANEL_FUSE_ROWS")) : 8192;
     auto factor_panel = [&](int64_t r0, int64_t w) -> int {
         for (int64_t c0 = r0; c0 < r0 + w; c0 += IB) {
             const int64_t kk = c0 - r0;
             if (kk > 0 && !panel_right)   // A[c0:pn, c0:c0+64] -= A[c0:pn, r0:c0] * A[c0:c0+64, r0:c0]^T
                 MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, pn - c0, IB, kk, A + c0 * lda + r0, lda, A + c0 * lda + r0, lda,
                                           A + c0 * lda + c0, lda));
-            MGPI_TRY(mgpi_launch_potf2(ctx, A + c0 * lda + c0, lda, c0, ctx->d_diag + c0));
-            MGPI_TRY(mgpi_launch_trsm_rows(ctx, A + c0 * lda + c0, lda, A + (c0 + IB) * lda + c0, lda, pn - c0 - IB));
+            if (panel_fused && pn - c0 - IB <= fuse_rows) {
+                MGPI_TRY(mgpi_launch_potf2_trsm(ctx, A + c0 * lda + c0, lda, c0, ctx->d_diag + c0, pn - c0 - IB,
+                                                ctx->d_diag + ctx->diag_len + c0 * IB));
+            } else {
+                MGPI_TRY(mgpi_launch_potf2(ctx, A + c0 * lda + c0, lda, c0, ctx->d_diag + c0));
+                MGPI_TRY(mgpi_launch_trsm_rows(ctx, A + c0 * lda + c0, lda, A + (c0 + IB) * lda + c0, lda, pn - c0 - IB));
+            }
             const int64_t c1 = c0 + IB, rest = r0 + w - c1;
             if (panel_right && rest > 0)  // A[c1:pn, c1:r0+w] -= A[c1:pn, c0:c1] * A[c1:r0+w, c0:c1]^T
                 MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, pn - c1, rest, IB, A + c1 * lda + c0, lda, A + c1 * lda + c0, lda,
@@ -532,6 +632,13 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
     }
     if (lookahead && panel_on_side) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
 
+    if (panel_fused) {   // the diagonal blocks factored by potf2_trsm_kernel wait in the scratch strip
+        int64_t first = (pn - IB - fuse_rows + IB - 1) / IB;          // smallest k with pn - 64 k - 64 <= fuse_rows
+        if (first < 0) first = 0;
+        if (first < pn / IB)
+            hipLaunchKernelGGL(diag_blocks_back_kernel, dim3((unsigned)(pn / IB - first)), dim3(256), 0, ctx->stream, A, lda,
+                               ctx->d_diag + ctx->diag_len, first);
+    }
     mgpi_prof_end(ctx, 2);
 
     hipLaunchKernelGGL(logdiag_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, n, ctx->d_scal);
