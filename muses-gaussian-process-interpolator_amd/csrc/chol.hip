@@ -696,32 +696,54 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
             }
             return 0;
         };
-        // look-ahead as in the factorisation: the update of the next outer block's rows and then their solve run on
+        // look-ahead as in the factorisation: the update of the next (super-)block's rows and then their solve run on
         // the second stream (the solve with lean kernels) while the update of all the rows below runs on the main
-        // stream at the same time - disjoint rows of B, both only read the solved rows of block k
+        // stream at the same time - disjoint rows of B, both only read the solved rows of block k.
+        // Two-level blocking, as in the factorisation: with the inverse diagonal blocks the solve of a block is cheap,
+        // so while many rows remain the big update is applied once per SUPER-BLOCK of MGPI_TRSM_SUPER (default 4)
+        // blocks, i.e. with a contraction of 2048 (NN gemm alone at 32768 x 4096: 62 / 69 / 71 TFLOP/s for K = 512 / 1024 /
+        // 2048).  C3 variance: 72.5 ms with 1 block per update, 71.1 with 2, 69.8 with 4, 72.1 with 8, 76.0 with 16.
+        static const int64_t super_blocks = getenv("MGPI_TRSM_SUPER") ? atoll(getenv("MGPI_TRSM_SUPER")) : 4;
+        static const int64_t super_min = getenv("MGPI_TRSM_SUPER_MIN") ? atoll(getenv("MGPI_TRSM_SUPER_MIN")) : 8192;
+        auto super_width = [&](int64_t r0) -> int64_t {
+            const int64_t left = pn - r0;
+            int64_t wc = (T != nullptr && r0 > 0 && left - super_blocks * nb >= super_min) ? super_blocks * nb : nb;
+            return wc < left ? wc : left;
+        };
+        // rows [r0, r0 + wc) of B <- (L restricted to that diagonal super-block)^-1 B: block by block, right-looking
+        auto solve_super = [&](int64_t r0, int64_t wc, bool on_side) -> int {
+            for (int64_t p0 = r0; p0 < r0 + wc; p0 += nb) {
+                const int64_t w = (r0 + wc - p0 < nb) ? (r0 + wc - p0) : nb;
+                ctx->lean = on_side ? 1 : 0;
+                int rc = solve_diag_block(p0, w);
+                ctx->lean = 0;
+                if (rc) return rc;
+                const int64_t p1 = p0 + w, rem = r0 + wc - p1;
+                if (rem > 0)    // B[p1:r0+wc,:] -= L[p1:r0+wc, p0:p1] * B[p0:p1,:]
+                    MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, rem, nc, w, L + p1 * lda + p0, lda, B + p0 * ldb, ldb, B + p1 * ldb, ldb));
+            }
+            return 0;
+        };
         hipStream_t main_stream = ctx->stream;
         const bool lookahead = ctx->stream2 != nullptr && !ctx->no_lookahead;
-        MGPI_TRY(solve_diag_block(0, (pn < nb) ? pn : nb));
+        int64_t wc = super_width(0);
+        MGPI_TRY(solve_super(0, wc, false));
         if (lookahead) MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
         bool block_on_side = false;
-        for (int64_t r0 = 0; r0 < pn; r0 += nb) {
-            const int64_t w = (pn - r0 < nb) ? (pn - r0) : nb;
+        for (int64_t r0 = 0; r0 < pn;) {
+            const int64_t w = wc;
             const int64_t t = pn - r0 - w;
             if (t <= 0) break;
             const int64_t r1 = r0 + w;
-            const int64_t w1 = (pn - r1 < nb) ? (pn - r1) : nb;
+            const int64_t w1 = super_width(r1);
             const int64_t t2 = t - w1;
             if (lookahead) {
                 if (block_on_side) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));   // rows of block k solved
-                // second stream: B[r1:r1+w1,:] -= L[r1:r1+w1, r0:r0+w] * B[r0:r0+w,:], then solve that block
+                // second stream: B[r1:r1+w1,:] -= L[r1:r1+w1, r0:r0+w] * B[r0:r0+w,:], then solve that (super-)block
                 MGPI_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_upd, 0));                        // update k-1 of these rows done
                 ctx->stream = ctx->stream2;
                 int rc = mgpi_launch_gemm(ctx, 0, 1, 0, w1, nc, w, L + r1 * lda + r0, lda, B + r0 * ldb, ldb, B + r1 * ldb, ldb);
-                if (rc == 0) {
-                    ctx->lean = 1;
-                    rc = solve_diag_block(r1, w1);
-                    ctx->lean = 0;
-                }
+                if (rc == 0) rc = solve_super(r1, w1, true);
                 ctx->stream = main_stream;
                 MGPI_TRY(rc);
                 MGPI_HIP_TRY(hipEventRecord(ctx->ev_panel, ctx->stream2));
@@ -733,11 +755,13 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
                 MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
             } else {
                 MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, w1, nc, w, L + r1 * lda + r0, lda, B + r0 * ldb, ldb, B + r1 * ldb, ldb));
-                MGPI_TRY(solve_diag_block(r1, w1));
+                MGPI_TRY(solve_super(r1, w1, false));
                 if (t2 > 0)
                     MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, t2, nc, w, L + (r1 + w1) * lda + r0, lda, B + r0 * ldb, ldb,
                                               B + (r1 + w1) * ldb, ldb));
             }
+            r0 = r1;
+            wc = w1;
         }
         if (lookahead && block_on_side) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
         if (T != nullptr) mgpi_pool_free(ctx, T, tbytes);      // reuse is ordered on the main stream, which has just joined

@@ -219,7 +219,9 @@ def test_trtri_neg_strided_batch(ctx, w, batch, row_step, col_step):
                                  {'MGPI_NO_LOOKAHEAD': '1'}, {'MGPI_POOL_MB': '0'}, {'MGPI_HIP_RUNTIME': 'system'},
                                  {'MGPI_SUPER_PANELS': '1', 'MGPI_SUPER_MIN': '512'}, {'MGPI_SUPER_PANELS': '2', 'MGPI_SUPER_MIN': '512'},
                                  {'MGPI_SUPER_PANELS': '4', 'MGPI_SUPER_MIN': '512'}, {'MGPI_VAR_DINV': '0'}, {'MGPI_PANEL_RIGHT': '0'}, {'MGPI_PANEL_FUSE': '0'},
-                                 {'MGPI_PANEL_FUSE_ROWS': '1000000', 'MGPI_SUPER_MIN': '512'}, {}],
+                                 {'MGPI_PANEL_FUSE_ROWS': '1000000', 'MGPI_SUPER_MIN': '512'},
+                                 {'MGPI_TRSM_SUPER': '1', 'MGPI_TRSM_SUPER_MIN': '512'}, {'MGPI_TRSM_SUPER': '2', 'MGPI_TRSM_SUPER_MIN': '512'},
+                                 {'MGPI_TRSM_SUPER': '4', 'MGPI_TRSM_SUPER_MIN': '512'}, {}],
                          ids=lambda e: ','.join('%s=%s' % kv for kv in e.items()) or 'defaults')
 def test_developer_switch_variants(env):
     """every kernel variant kept behind an environment switch (DESIGN.md section c) computes the same results:

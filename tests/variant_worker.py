@@ -51,7 +51,7 @@ ll = it.loglikelihood(x, f)
 s, logdet = np.linalg.slogdet(K)
 assert abs(ll - (-0.5 * f @ alpha - 0.5 * logdet - 0.5 * n * np.log(2 * np.pi))) < 1e-9 * abs(ll)
 assert np.all(var > 0) and np.all(var < 1.0)
-if os.environ.get('MGPI_SUPER_MIN'):
+if os.environ.get('MGPI_SUPER_MIN') or os.environ.get('MGPI_TRSM_SUPER_MIN'):
     # large enough for the two-level schedule to engage with the threshold the test sets; residual check only
     n = 4600
     x = rng.random((n, 3))
@@ -63,5 +63,13 @@ if os.environ.get('MGPI_SUPER_MIN'):
     s, logdet = np.linalg.slogdet(K)
     ll = it.loglikelihood(x, f)
     assert abs(ll - (-0.5 * f @ alpha - 0.5 * logdet - 0.5 * n * np.log(2 * np.pi))) < 1e-9 * abs(ll)
+    xs = rng.random((700, 3))
+    mean, var = it.condition_diag(xs, x, f)
+    Ks = mgpi.Interpolator._x2cov(xs, x, it.kernel)
+    Lc = np.linalg.cholesky(K)
+    from scipy.linalg import solve_triangular
+    V = solve_triangular(Lc, Ks.T, lower=True)
+    assert np.max(np.abs(mean - Ks @ alpha)) < 1e-10 * np.max(np.abs(mean))
+    assert np.max(np.abs(var - (1.0 - np.sum(V * V, axis=0)))) < 1e-9
 ctx.trim()
 print('VARIANT-OK', flush=True)

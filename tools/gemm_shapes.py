@@ -8,7 +8,7 @@ from mgpi_amd import _lib
 
 ctx = mgpi.default_context()
 rng = np.random.default_rng(0)
-k = 512
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 for m, n in [(32768, 4096), (16384, 4096), (4096, 4096), (32768, 512)]:
     A = _lib.DeviceMatrix.from_host(ctx, rng.standard_normal((m, k)), wide=True)
     Bt = _lib.DeviceMatrix.from_host(ctx, rng.standard_normal((n, k)), wide=True)      # NT: B given as n x k
