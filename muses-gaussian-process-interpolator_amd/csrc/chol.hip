@@ -672,6 +672,12 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
             MGPI_TRY(ensure_dinv(ctx, Lm));
             MGPI_TRY(mgpi_pool_alloc(ctx, (size_t)nb * (size_t)nc * sizeof(double), &T, &tbytes));
         }
+        struct scratch_guard {      // T goes back to the pool on every way out (reuse is ordered on the main stream, which
+            mgpi_ctx* c;            // has joined the second one by then - or the call failed and nothing runs on T any more)
+            double*& p;
+            size_t& b;
+            ~scratch_guard() { if (p) mgpi_pool_free(c, p, b); }
+        } release_T{ctx, T, tbytes};
         // rows [r0, r0+w) of B <- L_bb^-1 (rows of B): 64-wide inner blocks, left-looking inside the outer block
         auto solve_diag_block = [&](int64_t r0, int64_t w) -> int {
             if (T != nullptr) {
@@ -764,7 +770,6 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
             wc = w1;
         }
         if (lookahead && block_on_side) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
-        if (T != nullptr) mgpi_pool_free(ctx, T, tbytes);      // reuse is ordered on the main stream, which has just joined
     } else {
         const int64_t nblk = (pn + nb - 1) / nb;
         for (int64_t b = nblk - 1; b >= 0; --b) {
