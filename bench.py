@@ -89,6 +89,30 @@ def syrk_launch_flops(n, nb=NB):
     return total
 
 
+def syrk_schedule_flops(n, nb=NB, panels=2, super_min=14336):
+    """the same count for the shipped two-level schedule (csrc/chol.hip, super_width): the very first update is one
+    panel wide, then `panels` panels per update while at least `super_min` rows would remain behind the super-panel.
+    Cross-check for the number the library reports (mgpi_ctx_get_profile_flops); tests/ compare the two on the GPU."""
+    pn = (n + 127) // 128 * 128
+
+    def width(c0):
+        left = pn - c0
+        w = panels * nb if (c0 > 0 and left - panels * nb >= super_min) else nb
+        return min(w, left)
+
+    total, r0, wc = 0.0, 0, width(0)
+    while True:
+        t = pn - r0 - wc
+        if t <= 0:
+            return total
+        r1 = r0 + wc
+        w1 = width(r1)
+        t2 = t - w1
+        if t2 > 0:
+            total += t2 * (t2 + 1.0) * wc
+        r0, wc = r1, w1
+
+
 class GpuStep(object):
     """device-resident inputs + one hot-path pass through the C-ABI"""
 

@@ -11,6 +11,10 @@ def test_flop_formulas_match_survey_8d():
     assert abs(t / (32768**3 / 3.0) - 0.977) < 2e-3
     # the look-ahead split: syrk launches + next-panel column updates (t * nb * nb * 2 each, minus nothing) ~ the total
     assert bench.syrk_launch_flops(32768) < t and bench.syrk_launch_flops(32768) > 0.93 * t
+    # the shipped schedule (two panels per update above 14336 trailing rows) moves a little more of it into the column
+    # updates; profiles/r01_c3_bench.json records the library's own count of exactly this number
+    assert bench.syrk_schedule_flops(32768) == 10320634183680.0
+    assert bench.syrk_schedule_flops(32768, panels=1) == bench.syrk_launch_flops(32768)
     n, m = 32768, 4096
     assert bench.step_flops(n, m) == n**3 / 3.0 + 2.0 * n * n + float(n) * n * m + 2.0 * m * n
 

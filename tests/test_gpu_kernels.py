@@ -190,6 +190,23 @@ def test_gemm_staircase_matches_block_cyclic_definition(ctx, P, p, Q, q, bi0, bj
     assert np.array_equal(got[~live], C[~live])
 
 
+def test_profile_counts_the_flops_of_the_schedule(ctx):
+    """the roofline's numerator: the library's own count of the lower-syrk launches' algorithmic flops (profile slot 0)
+    equals the closed form of the shipped schedule in bench.py - at a size where the two-level schedule engages"""
+    import bench
+    n = 17000
+    rng = np.random.default_rng(1)
+    x = rng.random((n, 3))
+    it = mgpi.Interpolator(mgpi.SquaredExponentialKernel(1.0, 0.06, 0.06, 0.06), nugget=mgpi.WhiteNoiseKernel(0.1), context=ctx)
+    ctx.set_profile(True)
+    it.fit(x)
+    flops = ctx.get_profile_flops(0)
+    ms, launches = ctx.get_profile(0)
+    ctx.set_profile(False)
+    assert flops == bench.syrk_schedule_flops(n) and flops != bench.syrk_launch_flops(n)
+    assert launches > 0 and ms > 0
+
+
 @pytest.mark.parametrize('w,batch,row_step,col_step', [(64, 1, 0, 0), (128, 3, 256, 128), (512, 2, 512, 1024), (256, 5, 256, 256)])
 def test_trtri_neg_strided_batch(ctx, w, batch, row_step, col_step):
     """-(block)^-1 for lower-triangular blocks at a constant stride (the diagonal blocks a rank owns in a block-cyclic
