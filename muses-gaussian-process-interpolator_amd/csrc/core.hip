@@ -519,6 +519,18 @@ int mgpi_make_terms(const mgpi_kernel_desc* terms, int nterms, int d, mgpi_terms
                 const double c1 = 0.5772156649015329, c3 = -0.0420026350340952, c5 = -0.0421977345555443, m2 = mu * mu;
                 out->mat_gam1[t] = -(c1 + m2 * (c3 + m2 * c5));
             }
+            // o = p + 1/2: K_o is elementary and the shape function collapses to
+            //   exp(-x) * p!/(2p)! * sum_{i=0..p} (2p - i)! / ((p - i)! i!) * (2 x)^i      (1, 1 + x, 1 + x + x^2/3, ...)
+            out->mat_half_p[t] = -1;
+            const double twice = 2.0 * o;
+            if (twice == floor(twice) && ((long long)twice & 1) && o <= 0.5 + (MGPI_MATERN_POLY - 1)) {
+                const int p = (int)((twice - 1.0) * 0.5);
+                out->mat_half_p[t] = p;
+                for (int i = 0; i < MGPI_MATERN_POLY; ++i) out->mat_poly[t][i] = 0.0;
+                for (int i = 0; i <= p; ++i)
+                    out->mat_poly[t][i] = exp(lgamma(p + 1.0) - lgamma(2.0 * p + 1.0) + lgamma(2.0 * p - i + 1.0) - lgamma(p - i + 1.0) -
+                                              lgamma(i + 1.0) + i * log(2.0));
+            }
         }
     }
     return 0;

@@ -115,7 +115,12 @@ __device__ __forceinline__ double mgpi_cov_entry_range(const mgpi_terms_dev& t, 
                 if (k < nd) r = __dadd_rn(r, __dmul_rn(diff2[k], t.inv_l2[s][k]));
             const double diff = sqrt(t.mat_two_o[s]) * sqrt(r);    // (2*o)**0.5 * sum(...)**0.5   (kernels.py:161)
             double m = 1.0;                                        // r -> 0 limit of the bracket below (the reference: NaN)
-            if (diff > 0.0)
+            if (t.mat_half_p[s] >= 0) {
+                // half-integer order: exp(-x) times a polynomial of degree p (Horner), no special function needed
+                double poly = 0.0;
+                for (int i = t.mat_half_p[s]; i >= 0; --i) poly = fma(poly, diff, t.mat_poly[s][i]);
+                m = exp(-diff) * poly;                             // = 1 at diff == 0
+            } else if (diff > 0.0)
                 m = mgpi_matern_shape(diff, t.mat_nl[s], t.mat_mu[s], t.mat_norm[s], t.mat_gam1[s], t.mat_gam2[s],
                                       t.mat_gampl[s], t.mat_gammi[s]);
             val = __dadd_rn(val, __dmul_rn(t.sig2[s], m));

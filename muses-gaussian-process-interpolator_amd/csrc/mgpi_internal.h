@@ -93,6 +93,7 @@ int mgpi_pool_alloc(mgpi_ctx* ctx, size_t bytes, double** out, size_t* got);
 void mgpi_pool_free(mgpi_ctx* ctx, void* ptr, size_t bytes);
 
 // ---- device-side kernel descriptor (passed by value as a kernel argument) -------------------
+#define MGPI_MATERN_POLY 11
 struct mgpi_terms_dev {
     int nterms;
     int d;
@@ -103,6 +104,9 @@ struct mgpi_terms_dev {
     int mat_nl[MGPI_MAX_TERMS];
     double mat_mu[MGPI_MAX_TERMS], mat_two_o[MGPI_MAX_TERMS], mat_norm[MGPI_MAX_TERMS], mat_order[MGPI_MAX_TERMS];
     double mat_gam1[MGPI_MAX_TERMS], mat_gam2[MGPI_MAX_TERMS], mat_gampl[MGPI_MAX_TERMS], mat_gammi[MGPI_MAX_TERMS];
+    // half-integer orders o = p + 1/2 <= 10.5: the shape function is exp(-x) * sum_i mat_poly[i] x^i (closed form)
+    int mat_half_p[MGPI_MAX_TERMS];                  // p, or -1 for the general path
+    double mat_poly[MGPI_MAX_TERMS][MGPI_MATERN_POLY];
 };
 int mgpi_make_terms(const mgpi_kernel_desc* terms, int nterms, int d, mgpi_terms_dev* out);
 

@@ -151,7 +151,7 @@ class MaternKernel(NDKernel):
     """Matern(order, sigma, *lengths) (mgpi/kernels.py:135-162):
         r = sqrt(2 order sum_d ((x1_d - x2_d)/length_d)**2);  cov = sigma**2 2**(1-order)/Gamma(order) r**order K_order(r)
     evaluated on the GPU for any real order in (0, 120] (K_order by Temme's series / Steed's continued fraction,
-    csrc/cov_device.h, in the role of scipy.special.kv).  Deliberate deviation: at zero separation the reference
+    csrc/cov_device.h, in the role of scipy.special.kv; half-integer orders up to 10.5 by their closed form).  Deliberate deviation: at zero separation the reference
     computes 0**order * K(0) = 0 * inf = NaN (SURVEY.md section 0), which makes every source-source matrix unusable;
     here r == 0 gives the limit sigma**2."""
 
