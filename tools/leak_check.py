@@ -2,7 +2,7 @@
 """developer probe: device memory across a few hundred calls of varying size (pool, cached inverses, workspaces)"""
 import os, sys, ctypes
 import numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mgpi_amd as mgpi
 mgpi._lib.load_library()
 hip = ctypes.CDLL(None)      # the HIP runtime the library bound to (one runtime per process, see _lib.py)

@@ -1,6 +1,8 @@
+#!/usr/bin/env python3
+"""developer probe: kernel-matrix build rate per kernel type (SE, Matern half-integer closed form, Matern general path)"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mgpi_amd as mgpi
 rng = np.random.default_rng(0)
 n = 8192
