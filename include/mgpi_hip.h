@@ -55,7 +55,8 @@ typedef struct mgpi_kernel_desc {
     int32_t type;                 /* MGPI_TERM_* */
     int32_t reserved;
     double  sigma;                /* params[0] of SE / WhiteNoise, params[1] of Matern */
-    double  order;                /* Matern order o > 0 (params[0] of MaternKernel); unused otherwise */
+    double  order;                /* Matern order, 0 < o <= 120 (params[0] of MaternKernel); unused otherwise.  Half-integer
+                                   * orders up to 10.5 are evaluated by their closed form, the rest by Temme / Steed */
     double  length[MGPI_MAX_D];   /* SE: params[1:1+D]; Matern: params[2:2+D] */
 } mgpi_kernel_desc;
 
