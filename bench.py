@@ -44,6 +44,10 @@ WORKLOADS = {
     # name: (grid, D, M, seed)  - SURVEY.md section 8d recipes
     'c2': ((32, 16, 16), 3, 4096, 2),
     'c3': ((32, 32, 32), 3, 4096, 3),
+    'c4': ((16, 16, 16, 16), 4, 4096, 4),   # BASELINE.json configs[3] on ONE GPU (34 GB factor; 288 GB HBM)
+    # BASELINE.json configs[4]: stellarcollapse-shaped table, 1e6 queries, mean + variance (make_c5)
+    'c5': (5, 3, 1000000, None),            # per-axis downsample 5  -> N = 13160
+    'c5s': (10, 3, 1000000, None),          # per-axis downsample 10 -> N = 1680 (sc-eos-test's own setting)
 }
 # weak-scaling series for N > 1 GPU: N ~ 32768 * G^(1/3), a multiple of nb * lcm(P, Q)
 MULTI = {
@@ -63,6 +67,36 @@ def make_inputs(n_side, m, seed):
     xs = rng.random((m, len(n_side)))
     ell = tuple(2.0 / np.array(n_side, dtype=float))
     return x, f, xs, ell
+
+
+def make_c5(ds, m_side=100):
+    """BASELINE.json configs[4] on synthetic data of the stellarcollapse table's shape (the real
+    LS180 table is fetched by wget in the reference, etc/stellarcollapse-eos/fetch:13-56, and is not available):
+    axes ye(50) x logtemp(136) x logrho(234) (etc/example-stellarcollapse-data.ini:6-8, io.py:242-251), a smooth
+    logenergy(ye, logT, logrho) monotone in logT, x = (ye, logrho, logenergy), f = logtemp; per-axis decimation by
+    `ds` as test/stellarcollapse-eos/sc-eos-test:105-109; sigma = 2 std f, ell = 2 spacing, nugget sigma/100
+    (sc-eos-test:132-148); queries = regular m_side^3 grid over the table's extent (sc-eos-test:172-176)."""
+    ye = np.linspace(0.035, 0.53, 50)[::ds]
+    lt = np.linspace(-2.0, 2.4, 136)[::ds]
+    lr = np.linspace(3.0, 15.4, 234)[::ds]
+    Y, T, R = np.meshgrid(ye, lt, lr, indexing='ij')
+    loge = 17.0 + 1.1 * T + 0.25 * (R - 9.0) + 0.4 * Y + 0.05 * np.sin(R) * T
+    x = np.transpose([Y.ravel(), R.ravel(), loge.ravel()])
+    f = T.ravel() - np.mean(T)
+    sigma = 2 * np.std(f)
+    ell = tuple(2 * (np.ptp(x[:, k]) / (len(ax) - 1)) for k, ax in enumerate([ye, lr, lt]))
+    q = [np.linspace(x[:, k].min(), x[:, k].max(), m_side) for k in range(3)]
+    xs = np.transpose([a.ravel() for a in np.meshgrid(*q, indexing='ij')])
+    return x, f, xs, ell, sigma, sigma / 100.0
+
+
+def make_workload(name):
+    """x, f, xs, ell, sigma, nugget sigma of a single-GPU workload"""
+    spec = WORKLOADS[name]
+    if name.startswith('c5'):
+        return make_c5(spec[0])
+    x, f, xs, ell = make_inputs(spec[0], spec[2], spec[3])
+    return x, f, xs, ell, 1.0, 1e-2
 
 
 def step_flops(n, m):
@@ -116,7 +150,7 @@ def syrk_schedule_flops(n, nb=NB, panels=2, super_min=14336):
 class GpuStep(object):
     """device-resident inputs + one hot-path pass through the C-ABI"""
 
-    def __init__(self, x, f, xs, ell):
+    def __init__(self, x, f, xs, ell, sigma=1.0, nugget_sigma=1e-2):
         import ctypes
         import mgpi_amd as mgpi
         from mgpi_amd import _lib
@@ -124,8 +158,8 @@ class GpuStep(object):
         self.ctx = mgpi.default_context()
         self.lib = self.ctx.lib
         self.n, self.m = len(x), len(xs)
-        k = mgpi.SquaredExponentialKernel(1.0, *ell)
-        nug = mgpi.WhiteNoiseKernel(1e-2)
+        k = mgpi.SquaredExponentialKernel(sigma, *ell)
+        nug = mgpi.WhiteNoiseKernel(nugget_sigma)
         self.kdesc = _lib.make_terms(k.terms())
         self.sdesc = _lib.make_terms(k.terms() + nug.terms())
         DM = _lib.DeviceMatrix
@@ -148,6 +182,26 @@ class GpuStep(object):
                                     self.alpha.handle, self.mean.handle))
         c(lib.mgpi_predict_var_dev(h, self.XS.handle, self.X.handle, self.kdesc[0], self.kdesc[1], self.L.handle, 0,
                                    self.var.handle))
+
+
+    def run_staged(self):
+        """one pass with a tic/toc pair around every stage (untimed extra of bench.py): ms per stage"""
+        c, h, lib, ctx = self.lib_mod.check, self.ctx.handle, self.lib, self.ctx
+        out = {}
+
+        def stage(name, fn):
+            ctx.tic()
+            fn()
+            out[name] = ctx.toc()
+        stage('build_K_lower', lambda: c(lib.mgpi_cov_matrix_dev(h, self.X.handle, None, self.sdesc[0], self.sdesc[1], 1, self.L.handle)))
+        stage('potrf', lambda: c(lib.mgpi_potrf_dev(h, self.L.handle, None)))
+        c(lib.mgpi_mat_copy(h, self.F.handle, self.alpha.handle))
+        stage('potrs', lambda: c(lib.mgpi_potrs_dev(h, self.L.handle, self.alpha.handle)))
+        stage('predict_mean', lambda: c(lib.mgpi_predict_mean_dev(h, self.XS.handle, self.X.handle, self.kdesc[0], self.kdesc[1],
+                                                                  self.alpha.handle, self.mean.handle)))
+        stage('predict_var', lambda: c(lib.mgpi_predict_var_dev(h, self.XS.handle, self.X.handle, self.kdesc[0], self.kdesc[1],
+                                                                self.L.handle, 0, self.var.handle)))
+        return out
 
 
 class DistributedStep(object):
@@ -244,9 +298,9 @@ def main():
             dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     if not distributed:
-        n_side, d, m, seed = WORKLOADS[args.workload]
-        x, f, xs, ell = make_inputs(n_side, m, seed)
-        step = GpuStep(x, f, xs, ell)
+        d, m = WORKLOADS[args.workload][1], WORKLOADS[args.workload][2]
+        x, f, xs, ell, sigma, nugget_sigma = make_workload(args.workload)
+        step = GpuStep(x, f, xs, ell, sigma, nugget_sigma)
         name, par = args.workload.upper(), 'single GPU'
     else:
         assert force_dist or world in MULTI, 'supported GPU counts: 1, %s' % sorted(MULTI)
@@ -282,25 +336,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # untimed extra: the same kernel with the look-ahead off, i.e. without a panel factorisation running beside it
-    iso = None
+    c5 = (not distributed) and args.workload.startswith('c5')
+    slot = 4 if c5 else 0      # the dominant kernel: NN update gemm of the variance solve (C5) / lower syrk of the factorisation
+    # untimed extras: (a) the same kernel with the look-ahead off, i.e. without a panel factorisation running beside it,
+    # (b) one pass with a HIP-event pair around every stage
+    iso, stages = None, None
     if not distributed:
-        timed = [ctx.get_profile(i) for i in range(4)]
-        timed_flops = ctx.get_profile_flops(0)
+        timed = [ctx.get_profile(i) for i in range(6)]
+        timed_flops = ctx.get_profile_flops(slot)
+        timed_pairs = ctx.get_profile_flops(5)
         ctx.set_lookahead(False)
         ctx.set_profile(True)
         step.run()
         ctx.sync()
-        iso_ms, iso_launches = ctx.get_profile(0)
-        iso_flops = ctx.get_profile_flops(0)
+        iso_ms, iso_launches = ctx.get_profile(slot)
+        iso_flops = ctx.get_profile_flops(slot)
         ctx.set_lookahead(True)
-        iso = iso_flops / (iso_ms * 1e-3) / 1e12
-        (syrk_ms, syrk_launches), (panel_ms, _), (potrf_ms, _), (colupd_ms, colupd_launches) = timed
+        ctx.set_profile(False)
+        iso = iso_flops / (iso_ms * 1e-3) / 1e12 if iso_ms > 0 else None
+        stages = step.run_staged()
+        (syrk_ms, syrk_launches), (panel_ms, _), (potrf_ms, _), (colupd_ms, colupd_launches) = timed[:4]
+        dom_ms, dom_launches = timed[slot]
     else:
         syrk_ms, syrk_launches = ctx.get_profile(0)
         panel_ms, _ = ctx.get_profile(1)
         potrf_ms, _ = ctx.get_profile(2)
         colupd_ms, colupd_launches = ctx.get_profile(3)
+        dom_ms, dom_launches = syrk_ms, syrk_launches
     ctx.set_profile(False)
 
     if rank == 0:
@@ -310,29 +372,39 @@ def main():
             tr_flops = timed_flops / args.steps                    # reported by the library next to each launch
         else:
             tr_flops = step.gp.trailing_flops / (args.steps + args.warmup)      # this rank's share, per step
-        tflops_syrk = tr_flops * args.steps / (syrk_ms * 1e-3) / 1e12
+        tflops_dom = tr_flops * args.steps / (dom_ms * 1e-3) / 1e12
+        if c5:
+            kernel_name = 'gemm_f64_pipe_kernel<NN> (update launches of V = L^-1 K*^T, the variance solve)'
+            data_desc = 'stellarcollapse-shaped table (ye x logrho x logenergy -> logtemp, per-axis downsample %d)' % WORKLOADS[args.workload][0]
+        else:
+            kernel_name = 'gemm_f64_pipe_kernel<NT%s> (Cholesky trailing update%s)' % ((',lower', ', syrk') if not distributed else ('', ', rank 0 local blocks'))
+            data_desc = 'jittered grid'
         out = {
             'metric': 'condition+predict achieved fp64 TFLOP/s (wall-clock in ms_per_step) at N training points',
             'value': value, 'unit': 'TFLOP/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': '%s: N=%d D=%d jittered grid, SquaredExponential + WhiteNoise nugget, blocked '
-                                   'Cholesky nb=%d, M=%d queries (mean+variance)' % (name, n, d, NB, m),
+            'config': {'workload': '%s: N=%d D=%d %s, SquaredExponential + WhiteNoise nugget, blocked '
+                                   'Cholesky nb=%d, M=%d queries (mean+variance)' % (name, n, d, data_desc, NB, m),
                        'N': n, 'D': d, 'M': m, 'nb': NB, 'parallelism': par},
-            'roofline': {'bound': 'mfma', 'achieved': tflops_syrk, 'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': tflops_syrk / PEAK_FP64_MFMA_TFLOPS,
+            'roofline': {'bound': 'mfma', 'achieved': tflops_dom, 'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': tflops_dom / PEAK_FP64_MFMA_TFLOPS,
                          'traffic': load_traffic(args.workload) if not distributed else None,
-                         'kernel': 'gemm_f64_pipe_kernel<NT%s> (Cholesky trailing update%s)' % ((',lower', ', syrk') if not distributed else ('', ', rank 0 local blocks')),
-                         'launches': int(syrk_launches), 'avg_launch_ms': syrk_ms / max(1, syrk_launches),
+                         'kernel': kernel_name,
+                         'launches': int(dom_launches), 'avg_launch_ms': dom_ms / max(1, dom_launches),
                          'algorithmic_flops_per_step': tr_flops,
-                         'note': 'timed region runs with look-ahead: the column update of the next panel (same gemm family, '
-                                 'other stream) and its factorisation share the GPU with this kernel; isolated_* = the '
-                                 'same launches with the look-ahead off',
+                         'note': 'timed region runs with look-ahead: the next block\'s update and solve/factorisation (same gemm '
+                                 'family, other stream) share the GPU with this kernel; isolated_* = the same launches with the '
+                                 'look-ahead off',
                          'isolated_achieved': iso, 'isolated_frac': (iso / PEAK_FP64_MFMA_TFLOPS) if iso else None},
             'stages_ms_per_step': {'potrf': potrf_ms / args.steps, 'potrf_trailing_update': syrk_ms / args.steps,
                                    'potrf_next_panel_column_update': colupd_ms / args.steps,
                                    'potrf_panels_not_overlapped': panel_ms / args.steps},
         }
+        if stages is not None:
+            out['stages_ms_one_pass'] = stages
+            out['predict_mean'] = {'pairs_per_s': timed_pairs / (timed[5][0] * 1e-3) if timed[5][0] > 0 else None,
+                                   'ms_per_step': timed[5][0] / args.steps}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))

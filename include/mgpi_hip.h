@@ -49,6 +49,7 @@ extern "C" {
 #define MGPI_ERR_HIP     (-2)  /* HIP runtime error (incl. no device) */
 #define MGPI_ERR_ALLOC   (-3)  /* device allocation failed */
 #define MGPI_ERR_STATE   (-4)  /* handle used in the wrong state (e.g. potrs on an unfactored matrix) */
+#define MGPI_ERR_COMM    (-5)  /* RCCL error (librccl not loadable, communicator failure); text via mgpi_last_error() */
 
 /* one summand of the (flattened) CombinedKernel, built from Kernel.params in summand order */
 typedef struct mgpi_kernel_desc {
@@ -75,6 +76,12 @@ int  mgpi_ctx_sync(mgpi_ctx* ctx);                 /* wait for all queued device
  * thousands of times, and a hipMalloc/hipFree pair per call costs more than the factorisation below N ~ 16384.
  * The pool is capped at a quarter of the device memory (MGPI_POOL_MB overrides, 0 disables); trim releases it. */
 int  mgpi_ctx_trim(mgpi_ctx* ctx);
+/* Positive-definiteness rule of the factorisations (dense and NNGP): pivot k must exceed tol * K_kk(original).
+ * Default 100 eps (MGPI_PIVOT_TOL overrides at ctx creation): it makes the exactly singular K of duplicated source
+ * rows fail, as the reference's inv does (LinAlgError), instead of factoring rounding noise.  It is STRICTER than
+ * LAPACK: an ill-conditioned but positive definite K (cond ~ 1/(100 eps)) that np.linalg.inv accepts
+ * (interpolators.py:92,179) is rejected.  tol = 0 gives LAPACK's plain "pivot > 0" rule. */
+int  mgpi_ctx_set_pivot_tol(mgpi_ctx* ctx, double tol);
 /* raw hipStream_t of the ctx (as void*), for callers that time with HIP events */
 void* mgpi_ctx_stream(mgpi_ctx* ctx);
 /* event timing on the ctx stream: tic records, toc records+synchronises and returns ms */
@@ -101,6 +108,8 @@ int  mgpi_mat_symmetrize(mgpi_ctx* ctx, mgpi_mat* m);
 int  mgpi_mat_tril(mgpi_ctx* ctx, mgpi_mat* m);
 /* diag (n x 1 vector) <- diagonal of the square matrix m */
 int  mgpi_mat_diag(mgpi_ctx* ctx, const mgpi_mat* m, mgpi_mat* diag);
+/* m[i][i] += shift (square): the jitter of rvs()'s retry loop stays on the device */
+int  mgpi_mat_add_diag(mgpi_ctx* ctx, mgpi_mat* m, double shift);
 /* m[i][j] <- m[i][j] / (s[i] * s[j]), s an (n x 1) vector: covariance -> correlation (interpolators.py:321) */
 int  mgpi_mat_unscale(mgpi_ctx* ctx, mgpi_mat* m, const mgpi_mat* s);
 
@@ -177,10 +186,53 @@ int  mgpi_trsm_right_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* A);
  * VARIANCE sweep only, where a diagonal-block solve then becomes one gemm (error budget: DESIGN.md); w % 64 == 0 */
 int  mgpi_trtri_neg_dev(mgpi_ctx* ctx, const mgpi_mat* A, int64_t r0, int64_t c0, int64_t row_step, int64_t col_step, int64_t w,
                         int batch, mgpi_mat* out);
+/* --- more pieces of the block-cyclic driver: everything it does to device memory goes through this library ---------- */
+/* factor K in place WITHOUT reading the result back: the first failing pivot (reported as pivot_base + k, 1-based) is
+ * min-accumulated in the ctx and sum log L_ii is added to a ctx accumulator; one status_read at the end of the whole
+ * factorisation replaces a host round trip per block step.  status_reset clears both. */
+int  mgpi_potrf_enqueue_dev(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base);
+int  mgpi_ctx_status_reset(mgpi_ctx* ctx);
+int  mgpi_ctx_status_read(mgpi_ctx* ctx, int64_t* pivot, double* logdiag);      /* synchronises ctx's stream */
+/* order two contexts of one device: what `signaler` has queued so far precedes what `waiter` queues from now on */
+int  mgpi_ctx_wait(mgpi_ctx* waiter, mgpi_ctx* signaler);
+/* m[i][i] = value, i < min(rows, cols) of the handle (use a view to address part of a diagonal) */
+int  mgpi_mat_fill_diag(mgpi_ctx* ctx, mgpi_mat* m, double value);
+/* y += a x, (n x 1) vectors */
+int  mgpi_axpy_dev(mgpi_ctx* ctx, double a, const mgpi_mat* x, mgpi_mat* y);
+/* `count` blocks of `rows` full-width rows: dst rows [dst_r0 + j dst_step, ..) <- src rows [src_r0 + j src_step, ..) */
+int  mgpi_copy_blocks_dev(mgpi_ctx* ctx, const mgpi_mat* src, int64_t src_r0, int64_t src_step, mgpi_mat* dst, int64_t dst_r0,
+                          int64_t dst_step, int64_t rows, int64_t count);
+/* out[c] = sum_r V[r][c]^2 over the padded rows of V; out a (cols x 1) vector */
+int  mgpi_colsq_dev(mgpi_ctx* ctx, const mgpi_mat* V, mgpi_mat* out);
+
 /* single-vector half-solve with a factored diagonal block (<= 4096 rows): L y = b (trans=0) / L^T x = b (trans=1) */
 int  mgpi_trsv_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* v, int trans);
 /* y -= A x (trans=0) or y -= A^T x (trans=1); x, y vectors (ld == 1) */
 int  mgpi_gemv_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* x, mgpi_mat* y, int trans);
+
+/* ---- RCCL over xGMI (north_star: "2D block-cyclic panels with RCCL broadcast/reduce over xGMI") ---
+ * One process per GPU.  Rank 0 makes a unique id and ships its MGPI_COMM_ID_BYTES bytes to the other ranks by any means
+ * (mgpi_amd.rendezvous uses a file: the ranks of one node share a filesystem); every rank then calls mgpi_comm_create
+ * with its ctx (the communicator lives on that ctx's GPU).  mgpi_comm_split makes the process-row / process-column
+ * communicators of the P x Q grid.  Collectives take device pointers to contiguous doubles and are enqueued on the
+ * stream of the ctx passed with them - a second ctx of the same device gives the look-ahead stream - with no host
+ * synchronisation.  librccl.so.1 is dlopen'ed on first use (MGPI_RCCL_LIB overrides the name); failures return
+ * MGPI_ERR_COMM.  Broadcasts are grouped point-to-point sends from the root (xGMI is point to point: the 1-3 peers of a
+ * grid row / column sit on separate links); MGPI_BCAST=rccl selects ncclBroadcast.
+ * The reference has no communication layer; these calls exist only because K no longer fits the role of ONE
+ * np.linalg.inv operand (interpolators.py:92,179) when it is spread over GPUs. */
+#define MGPI_COMM_ID_BYTES 128
+typedef struct mgpi_comm mgpi_comm;
+int  mgpi_comm_unique_id(void* out /* MGPI_COMM_ID_BYTES */);
+int  mgpi_comm_create(mgpi_ctx* ctx, const void* unique_id, int rank, int world, mgpi_comm** out);
+int  mgpi_comm_split(mgpi_comm* comm, int color, int key, mgpi_comm** out);   /* same color = same new communicator, ranked by key */
+int  mgpi_comm_destroy(mgpi_comm* comm);
+int  mgpi_comm_info(const mgpi_comm* comm, int* rank, int* size);
+int  mgpi_comm_bcast(mgpi_comm* comm, mgpi_ctx* ctx, double* buf, int64_t count, int root);
+int  mgpi_comm_reduce_sum(mgpi_comm* comm, mgpi_ctx* ctx, double* buf, int64_t count, int root);   /* in place on root */
+int  mgpi_comm_allreduce(mgpi_comm* comm, mgpi_ctx* ctx, double* buf, int64_t count, int op /* 0 sum, 1 max */);
+int  mgpi_comm_allgather(mgpi_comm* comm, mgpi_ctx* ctx, const double* send, double* recv, int64_t count);
+int  mgpi_comm_barrier(mgpi_comm* comm, mgpi_ctx* ctx);   /* all ranks arrived and ctx's stream drained */
 
 /* ---- NearestNeighborInterpolator (mgpi/interpolators.py:612-871) ----------------------
  * Host pointers in and out; the reference's own neighbour sets are host-side index lists too (:744, :833). */
@@ -211,10 +263,12 @@ int  mgpi_ctx_set_lookahead(mgpi_ctx* ctx, int on);
 /* per-kernel accumulated HIP-event time of the last mgpi_potrf_dev when profiling is enabled */
 int  mgpi_ctx_set_profile(mgpi_ctx* ctx, int on);
 /* which: 0 = trailing update (lower syrk launches), 1 = panel (potf2+trsm+inner gemm; only when look-ahead is off),
- * 2 = whole potrf, 3 = look-ahead update of the next panel's block column; ms and launches */
+ * 2 = whole potrf, 3 = look-ahead update of the next panel's block column, 4 = the big (main-stream) update launches of
+ * the multi-rhs forward solve V = L^-1 K*^T of the variance path, 5 = the fused predict-mean kernel; ms and launches */
 int  mgpi_ctx_get_profile(mgpi_ctx* ctx, int which, double* ms, int64_t* launches);
 /* algorithmic flops of the launches recorded in slot `which` since profiling was switched on: for slot 0 the sum of
- * t (t + 1) K over the lower-triangular trailing updates (t rows, contraction length K) */
+ * t (t + 1) K over the lower-triangular trailing updates (t rows, contraction length K); slot 4: 2 t m K of the
+ * solve's update launches; slot 5: the number of (query, source) kernel evaluations */
 int  mgpi_ctx_get_profile_flops(mgpi_ctx* ctx, int which, double* flops);
 
 #ifdef __cplusplus

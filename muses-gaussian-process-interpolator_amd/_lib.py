@@ -71,6 +71,8 @@ _SIGNATURES = {
     'mgpi_mat_tril': (ctypes.c_int, [_vp, _vp]),
     'mgpi_mat_diag': (ctypes.c_int, [_vp, _vp, _vp]),
     'mgpi_mat_unscale': (ctypes.c_int, [_vp, _vp, _vp]),
+    'mgpi_mat_add_diag': (ctypes.c_int, [_vp, _vp, ctypes.c_double]),
+    'mgpi_ctx_set_pivot_tol': (ctypes.c_int, [_vp, ctypes.c_double]),
     'mgpi_mat_view': (ctypes.c_int, [_vp, c_int64, c_int64, c_int64, c_int64, ctypes.POINTER(_vp)]),
     'mgpi_cov_paired': (ctypes.c_int, [_vp, _vp, _vp, c_int64, ctypes.c_int, ctypes.POINTER(KernelDesc), ctypes.c_int, _vp]),
     'mgpi_nn_neighbors': (ctypes.c_int, [_vp, _vp, _vp, c_int64, ctypes.c_int, _vp, _vp, c_int64, ctypes.c_int, ctypes.c_int, _vp, _vp]),
@@ -94,6 +96,24 @@ _SIGNATURES = {
     'mgpi_trsm_right_dev': (ctypes.c_int, [_vp, _vp, _vp]),
     'mgpi_trsv_dev': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
     'mgpi_gemv_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int]),
+    'mgpi_potrf_enqueue_dev': (ctypes.c_int, [_vp, _vp, c_int64]),
+    'mgpi_ctx_status_reset': (ctypes.c_int, [_vp]),
+    'mgpi_ctx_status_read': (ctypes.c_int, [_vp, ctypes.POINTER(c_int64), c_double_p]),
+    'mgpi_ctx_wait': (ctypes.c_int, [_vp, _vp]),
+    'mgpi_mat_fill_diag': (ctypes.c_int, [_vp, _vp, ctypes.c_double]),
+    'mgpi_axpy_dev': (ctypes.c_int, [_vp, ctypes.c_double, _vp, _vp]),
+    'mgpi_copy_blocks_dev': (ctypes.c_int, [_vp, _vp, c_int64, c_int64, _vp, c_int64, c_int64, c_int64, c_int64]),
+    'mgpi_colsq_dev': (ctypes.c_int, [_vp, _vp, _vp]),
+    'mgpi_comm_unique_id': (ctypes.c_int, [_vp]),
+    'mgpi_comm_create': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
+    'mgpi_comm_split': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_vp)]),
+    'mgpi_comm_destroy': (ctypes.c_int, [_vp]),
+    'mgpi_comm_info': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    'mgpi_comm_bcast': (ctypes.c_int, [_vp, _vp, _vp, c_int64, ctypes.c_int]),
+    'mgpi_comm_reduce_sum': (ctypes.c_int, [_vp, _vp, _vp, c_int64, ctypes.c_int]),
+    'mgpi_comm_allreduce': (ctypes.c_int, [_vp, _vp, _vp, c_int64, ctypes.c_int]),
+    'mgpi_comm_allgather': (ctypes.c_int, [_vp, _vp, _vp, _vp, c_int64]),
+    'mgpi_comm_barrier': (ctypes.c_int, [_vp, _vp]),
     'mgpi_probe_mfma_f64': (ctypes.c_int, [_vp, ctypes.c_int, c_double_p]),
     'mgpi_probe_hbm': (ctypes.c_int, [_vp, c_int64, ctypes.c_int, c_double_p, c_double_p]),
     'mgpi_ctx_set_lookahead': (ctypes.c_int, [_vp, ctypes.c_int]),
@@ -282,6 +302,10 @@ class Context(object):
         ms = ctypes.c_double(0.0)
         check(self.lib.mgpi_ctx_toc(self.handle, ctypes.byref(ms)))
         return ms.value
+
+    def set_pivot_tol(self, tol):
+        """pivot k must exceed tol * K_kk; default 100 eps, 0 = LAPACK's pivot > 0 (include/mgpi_hip.h)"""
+        check(self.lib.mgpi_ctx_set_pivot_tol(self.handle, float(tol)))
 
     def set_lookahead(self, on):
         check(self.lib.mgpi_ctx_set_lookahead(self.handle, int(bool(on))))

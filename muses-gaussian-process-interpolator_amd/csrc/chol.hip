@@ -25,7 +25,7 @@
 // pivots that are pure rounding noise.  The second part is what makes an exactly singular K - duplicated source
 // rows under the exact-equality white noise, where the reference's inv raises LinAlgError - fail here too
 // instead of returning garbage.
-#define MGPI_PIVOT_TOL 2.2e-14   /* 100 eps */
+// The threshold is ctx->pivot_tol (default 100 eps; mgpi_ctx_set_pivot_tol / MGPI_PIVOT_TOL; 0 = LAPACK's rule alone).
 
 // broadcast lane `l` (compile-time constant after unrolling) of a double to the whole wave: two v_readlane_b32
 __device__ __forceinline__ double readlane_f64(double v, int l) {
@@ -90,7 +90,7 @@ struct potf2_steps {
 // ~300 us for one of them to finish (an earlier single-wave version held the row in 128 VGPRs and a 33 KB
 // staging tile and did wait).
 __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int64_t lda, int64_t pivot_base,
-                                                    const double* __restrict__ diag0, int* __restrict__ info) {
+                                                    const double* __restrict__ diag0, int* __restrict__ info, double ptol) {
     __shared__ __attribute__((aligned(16))) double col[2][IB];
     __shared__ double dtol[IB];
     MGPI_CHAIN_PRIO();
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int6
         a[j] = (16 * q + j <= r) ? v.x : 0.0;           // only the lower triangle is read
         a[j + 1] = (16 * q + j + 1 <= r) ? v.y : 0.0;
     }
-    if (q == 0) dtol[r] = MGPI_PIVOT_TOL * fabs(diag0[r]);
+    if (q == 0) dtol[r] = ptol * fabs(diag0[r]);
     int bad = 0;
     potf2_steps<0>::run(a, col, dtol, r, q, bad);
 #pragma unroll
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int6
 }
 
 int mgpi_launch_potf2(mgpi_ctx* ctx, double* A, int64_t lda, int64_t pivot_base, const double* diag0) {
-    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, pivot_base, diag0, ctx->d_info);
+    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, pivot_base, diag0, ctx->d_info, ctx->pivot_tol);
     MGPI_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -230,7 +230,7 @@ int mgpi_launch_trsm_rows(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double*
 // latency hides behind it.  One kernel boundary less on the panel chain (potf2 26 us + trsm 22 us stand-alone).
 __global__ __launch_bounds__(256) void potf2_trsm_kernel(double* __restrict__ A, int64_t lda, int64_t pivot_base,
                                                          const double* __restrict__ diag0, int* __restrict__ info,
-                                                         double* __restrict__ S) {
+                                                         double* __restrict__ S, double ptol) {
     __shared__ __attribute__((aligned(16))) double col[2][IB];
     __shared__ double dtol[IB];
     __shared__ __attribute__((aligned(16))) double C[IB][IB];
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void potf2_trsm_kernel(double* __restrict__ A,
         a[j] = (16 * q + j <= r) ? v.x : 0.0;           // only the lower triangle is read
         a[j + 1] = (16 * q + j + 1 <= r) ? v.y : 0.0;
     }
-    if (q == 0) dtol[r] = MGPI_PIVOT_TOL * fabs(diag0[r]);
+    if (q == 0) dtol[r] = ptol * fabs(diag0[r]);
     double* xrow = A + ((int64_t)blockIdx.x * IB + r) * lda + 16 * q;     // workgroup b: rows [64 b, 64 b + 64) below the block's top
     double x[16];
     if (blockIdx.x > 0) {
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void diag_blocks_back_kernel(double* __restric
 int mgpi_launch_potf2_trsm(mgpi_ctx* ctx, double* A, int64_t lda, int64_t pivot_base, const double* diag0, int64_t rows, double* S) {
     MGPI_REQUIRE(rows % IB == 0, "potf2_trsm: rows=%lld not a multiple of %d", (long long)rows, IB);
     hipLaunchKernelGGL(potf2_trsm_kernel, dim3((unsigned)(1 + rows / IB)), dim3(256), 0, ctx->stream, A, lda, pivot_base, diag0,
-                       ctx->d_info, S);
+                       ctx->d_info, S, ctx->pivot_tol);
     MGPI_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -419,7 +419,7 @@ extern "C" int mgpi_trtri_neg_dev(mgpi_ctx* ctx, const mgpi_mat* A, int64_t r0, 
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
     MGPI_HIP_TRY(hipMemset2DAsync(out->d, (size_t)out->ld * sizeof(double), 0, (size_t)w * sizeof(double), (size_t)batch * w,
                                   ctx->stream));
-    out->factored = 0;
+    mgpi_mat_invalidate(out);
     return invert_lower_blocks(ctx, A->d + r0 * A->ld + c0, A->ld, row_step * A->ld + col_step, out->d, out->ld, w * out->ld, w, batch);
 }
 
@@ -443,8 +443,9 @@ __global__ void save_diag_kernel(const double* __restrict__ A, int64_t lda, int6
 }
 
 // out[0] = sum_i log(A[i][i]) over i < n (single workgroup, fixed summation order => deterministic)
+// accumulate != 0: out[0] += sum (the block-by-block factorisation of the multi-GPU driver)
 __global__ __launch_bounds__(256) void logdiag_kernel(const double* __restrict__ A, int64_t lda, int64_t n,
-                                                      double* __restrict__ out) {
+                                                      double* __restrict__ out, int accumulate) {
     __shared__ double part[256];
     double s = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += 256) s += log(A[i * lda + i]);
@@ -454,11 +455,16 @@ __global__ __launch_bounds__(256) void logdiag_kernel(const double* __restrict__
         if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = part[0];
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + part[0] : part[0];
 }
 
 // ---- the factorisation ----------------------------------------------------------------------------------
-extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
+// Enqueues the whole factorisation of K on ctx's streams and returns without a host synchronisation.
+//   pivot_base  global index of K's first row: a failing pivot k is reported as pivot_base + k (1-based)
+//   keep_status 0: the failing-pivot word is cleared first and sum log L_ii goes to d_scal[0] (mgpi_potrf_dev reads both)
+//               1: the failing pivot is min-accumulated into the ctx status word and sum log L_ii is ADDED to
+//                  d_scal[1] - the block-by-block factorisation of the multi-GPU driver reads them once at the end
+static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int keep_status) {
     MGPI_REQUIRE(ctx && K, "mgpi_potrf_dev: null pointer");
     MGPI_REQUIRE(K->rows == K->cols, "mgpi_potrf_dev: matrix is %lld x %lld, not square", (long long)K->rows, (long long)K->cols);
     MGPI_REQUIRE(K->pcols >= K->prows || K->pcols >= mgpi_roundup(K->rows, IB),
@@ -474,7 +480,7 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
     double* A = K->d;
     const int64_t nb = ctx->nb;
 
-    MGPI_HIP_TRY(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
+    if (!keep_status) MGPI_HIP_TRY(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
     if (pn > n) {
         hipLaunchKernelGGL(pad_identity_kernel, dim3((unsigned)((pn - n + 63) / 64)), dim3(64), 0, ctx->stream, A, lda, n, pn);
         MGPI_HIP_TRY(hipGetLastError());
@@ -517,10 +523,10 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
                 MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, pn - c0, IB, kk, A + c0 * lda + r0, lda, A + c0 * lda + r0, lda,
                                           A + c0 * lda + c0, lda));
             if (panel_fused && pn - c0 - IB <= fuse_rows) {
-                MGPI_TRY(mgpi_launch_potf2_trsm(ctx, A + c0 * lda + c0, lda, c0, ctx->d_diag + c0, pn - c0 - IB,
+                MGPI_TRY(mgpi_launch_potf2_trsm(ctx, A + c0 * lda + c0, lda, pivot_base + c0, ctx->d_diag + c0, pn - c0 - IB,
                                                 ctx->d_diag + ctx->diag_len + c0 * IB));
             } else {
-                MGPI_TRY(mgpi_launch_potf2(ctx, A + c0 * lda + c0, lda, c0, ctx->d_diag + c0));
+                MGPI_TRY(mgpi_launch_potf2(ctx, A + c0 * lda + c0, lda, pivot_base + c0, ctx->d_diag + c0));
                 MGPI_TRY(mgpi_launch_trsm_rows(ctx, A + c0 * lda + c0, lda, A + (c0 + IB) * lda + c0, lda, pn - c0 - IB));
             }
             const int64_t c1 = c0 + IB, rest = r0 + w - c1;
@@ -641,8 +647,15 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
     }
     mgpi_prof_end(ctx, 2);
 
-    hipLaunchKernelGGL(logdiag_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, n, ctx->d_scal);
+    hipLaunchKernelGGL(logdiag_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, n, ctx->d_scal + (keep_status ? 1 : 0),
+                       keep_status);
     MGPI_HIP_TRY(hipGetLastError());
+    K->factored = 1;          // mgpi_potrf_dev takes it back when the status says otherwise
+    return 0;
+}
+
+extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
+    MGPI_TRY(potrf_enqueue(ctx, K, 0, 0));
     int info = 0;
     double ld = 0.0;
     MGPI_HIP_TRY(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -650,11 +663,42 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
     MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (info != 0) {
         K->factored = 0;
-        mgpi_set_error("covariance is not positive definite! (pivot %d)", info);
+        mgpi_set_error("covariance is not positive definite! (pivot %d is not above %.3g times its original diagonal entry)", info,
+                       ctx->pivot_tol);
         return info;
     }
     if (logdet) *logdet = 2.0 * ld;
-    K->factored = 1;
+    return 0;
+}
+
+// The multi-GPU driver factors one nb x nb diagonal block per block step; reading the status back after each of them
+// would put a host round trip on the critical path of every step (round 1: 217 ms against 189 at N = 32768).  These three
+// keep the status on the device: reset once, enqueue the block factorisations, read once.
+extern "C" int mgpi_potrf_enqueue_dev(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base) {
+    MGPI_REQUIRE(pivot_base >= 0 && pivot_base < (int64_t)2147483647 - 70000, "mgpi_potrf_enqueue_dev: pivot_base out of range");
+    return potrf_enqueue(ctx, K, pivot_base, 1);
+}
+
+extern "C" int mgpi_ctx_status_reset(mgpi_ctx* ctx) {
+    MGPI_REQUIRE(ctx != nullptr, "mgpi_ctx_status_reset: null ctx");
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    MGPI_HIP_TRY(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
+    MGPI_HIP_TRY(hipMemsetAsync(ctx->d_scal + 1, 0, sizeof(double), ctx->stream));
+    return 0;
+}
+
+// *pivot: smallest 1-based global index of a failing pivot since the reset (0 = none); *logdiag: sum of log L_ii over
+// every block factored since the reset.  Synchronises ctx's stream.
+extern "C" int mgpi_ctx_status_read(mgpi_ctx* ctx, int64_t* pivot, double* logdiag) {
+    MGPI_REQUIRE(ctx != nullptr, "mgpi_ctx_status_read: null ctx");
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    int info = 0;
+    double ld = 0.0;
+    MGPI_HIP_TRY(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MGPI_HIP_TRY(hipMemcpyAsync(&ld, ctx->d_scal + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (pivot) *pivot = info;
+    if (logdiag) *logdiag = ld;
     return 0;
 }
 
@@ -755,9 +799,13 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
                 MGPI_HIP_TRY(hipEventRecord(ctx->ev_panel, ctx->stream2));
                 block_on_side = true;
                 // main stream: the remaining rows  B[r1+w1:,:] -= L[r1+w1:, r0:r0+w] * B[r0:r0+w,:]
-                if (t2 > 0)
+                if (t2 > 0) {
+                    mgpi_prof_begin(ctx, 4);
                     MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, t2, nc, w, L + (r1 + w1) * lda + r0, lda, B + r0 * ldb, ldb,
                                               B + (r1 + w1) * ldb, ldb));
+                    mgpi_prof_end(ctx, 4);
+                    mgpi_prof_flops(ctx, 4, 2.0 * (double)t2 * (double)nc * (double)w);
+                }
                 MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
             } else {
                 MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, w1, nc, w, L + r1 * lda + r0, lda, B + r0 * ldb, ldb, B + r1 * ldb, ldb));

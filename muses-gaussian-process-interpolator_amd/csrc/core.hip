@@ -47,7 +47,7 @@ extern "C" int mgpi_ctx_create(int device_id, int nb, mgpi_ctx** out) {
     mgpi_ctx* c = new (std::nothrow) mgpi_ctx();
     if (!c) { mgpi_set_error("mgpi_ctx_create: out of host memory"); return MGPI_ERR_ALLOC; }
     memset((void*)c, 0, sizeof(*c));
-    c->prof = new mgpi_prof_slot[4]();
+    c->prof = new mgpi_prof_slot[MGPI_PROF_SLOTS]();
     c->device = device_id;
     c->nb = nb;
     MGPI_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -58,7 +58,9 @@ extern "C" int mgpi_ctx_create(int device_id, int nb, mgpi_ctx** out) {
     }
     MGPI_HIP_TRY(hipEventCreateWithFlags(&c->ev_upd, hipEventDisableTiming));
     MGPI_HIP_TRY(hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming));
+    MGPI_HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     c->no_lookahead = getenv("MGPI_NO_LOOKAHEAD") && atoi(getenv("MGPI_NO_LOOKAHEAD")) != 0;
+    c->pivot_tol = getenv("MGPI_PIVOT_TOL") ? atof(getenv("MGPI_PIVOT_TOL")) : 100.0 * 2.220446049250313e-16;
     MGPI_HIP_TRY(hipEventCreate(&c->ev0));
     MGPI_HIP_TRY(hipEventCreate(&c->ev1));
     MGPI_HIP_TRY(hipMalloc((void**)&c->d_info, 64));
@@ -156,7 +158,7 @@ extern "C" int mgpi_ctx_destroy(mgpi_ctx* ctx) {
     (void)hipFree(ctx->d_scal);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < MGPI_PROF_SLOTS; ++s) {
         for (hipEvent_t e : ctx->prof[s].begin) (void)hipEventDestroy(e);
         for (hipEvent_t e : ctx->prof[s].end) (void)hipEventDestroy(e);
     }
@@ -165,6 +167,7 @@ extern "C" int mgpi_ctx_destroy(mgpi_ctx* ctx) {
     (void)hipStreamDestroy(ctx->stream2);
     (void)hipEventDestroy(ctx->ev_upd);
     (void)hipEventDestroy(ctx->ev_panel);
+    (void)hipEventDestroy(ctx->ev_join);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -173,6 +176,19 @@ extern "C" int mgpi_ctx_destroy(mgpi_ctx* ctx) {
 extern "C" int mgpi_ctx_sync(mgpi_ctx* ctx) {
     MGPI_REQUIRE(ctx != nullptr, "mgpi_ctx_sync: null ctx");
     MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// everything queued on `signaler`'s stream so far happens before whatever `waiter` enqueues from now on (two contexts
+// of one device: the main and the look-ahead stream of the multi-GPU driver); nothing waits on the host
+extern "C" int mgpi_ctx_wait(mgpi_ctx* waiter, mgpi_ctx* signaler) {
+    MGPI_REQUIRE(waiter && signaler, "mgpi_ctx_wait: null ctx");
+    MGPI_REQUIRE(waiter->device == signaler->device, "mgpi_ctx_wait: contexts on different devices (%d, %d)", waiter->device,
+                 signaler->device);
+    if (waiter == signaler) return 0;
+    MGPI_HIP_TRY(hipSetDevice(signaler->device));
+    MGPI_HIP_TRY(hipEventRecord(signaler->ev_join, signaler->stream));
+    MGPI_HIP_TRY(hipStreamWaitEvent(waiter->stream, signaler->ev_join, 0));
     return 0;
 }
 
@@ -200,11 +216,17 @@ extern "C" int mgpi_ctx_set_lookahead(mgpi_ctx* ctx, int on) {
     return 0;
 }
 
+extern "C" int mgpi_ctx_set_pivot_tol(mgpi_ctx* ctx, double tol) {
+    MGPI_REQUIRE(ctx != nullptr && tol >= 0.0 && tol < 1.0, "mgpi_ctx_set_pivot_tol: tolerance %g outside [0, 1)", tol);
+    ctx->pivot_tol = tol;
+    return 0;
+}
+
 extern "C" int mgpi_ctx_set_profile(mgpi_ctx* ctx, int on) {
     MGPI_REQUIRE(ctx != nullptr, "mgpi_ctx_set_profile: null ctx");
     MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->profile = on;
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < MGPI_PROF_SLOTS; ++s) {
         ctx->prof[s].used = 0;
         ctx->prof[s].ms = 0.0;
         ctx->prof[s].launches = 0;
@@ -215,7 +237,7 @@ extern "C" int mgpi_ctx_set_profile(mgpi_ctx* ctx, int on) {
 
 // sums the recorded event pairs (after draining the stream)
 extern "C" int mgpi_ctx_get_profile(mgpi_ctx* ctx, int which, double* ms, int64_t* launches) {
-    MGPI_REQUIRE(ctx != nullptr && which >= 0 && which < 4, "mgpi_ctx_get_profile: bad argument");
+    MGPI_REQUIRE(ctx != nullptr && which >= 0 && which < MGPI_PROF_SLOTS, "mgpi_ctx_get_profile: bad argument");
     MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
     mgpi_prof_slot& p = ctx->prof[which];
     double total = 0.0;
@@ -232,7 +254,7 @@ extern "C" int mgpi_ctx_get_profile(mgpi_ctx* ctx, int which, double* ms, int64_
 }
 
 extern "C" int mgpi_ctx_get_profile_flops(mgpi_ctx* ctx, int which, double* flops) {
-    MGPI_REQUIRE(ctx != nullptr && flops != nullptr && which >= 0 && which < 4, "mgpi_ctx_get_profile_flops: bad argument");
+    MGPI_REQUIRE(ctx != nullptr && flops != nullptr && which >= 0 && which < MGPI_PROF_SLOTS, "mgpi_ctx_get_profile_flops: bad argument");
     *flops = ctx->prof[which].flops;
     return 0;
 }
@@ -315,12 +337,26 @@ extern "C" int mgpi_mat_alloc_wide(mgpi_ctx* ctx, int64_t rows, int64_t cols, mg
     return mat_alloc_impl(ctx, rows, cols, 1, out);
 }
 
-extern "C" int mgpi_mat_free(mgpi_mat* m) {
-    if (!m) return 0;
+// the inverse-diagonal-block cache belongs to the handle that built it (views and wraps never share it)
+static void mat_drop_dinv(mgpi_mat* m) {
     if (m->dinv) {
         (void)hipSetDevice(m->ctx->device);
         pool_free(m->ctx, m->dinv, m->dinv_bytes);
     }
+    m->dinv = nullptr;
+    m->dinv_nb = 0;
+    m->dinv_bytes = 0;
+}
+
+// the contents of m are about to change: it is no longer a factor and its cached inverse blocks are stale
+void mgpi_mat_invalidate(mgpi_mat* m) {
+    m->factored = 0;
+    mat_drop_dinv(m);
+}
+
+extern "C" int mgpi_mat_free(mgpi_mat* m) {
+    if (!m) return 0;
+    mat_drop_dinv(m);
     if (m->owns && m->d) {
         (void)hipSetDevice(m->ctx->device);
         pool_free(m->ctx, m->d, m->alloc_bytes);
@@ -336,13 +372,21 @@ extern "C" int mgpi_mat_view(const mgpi_mat* m, int64_t r0, int64_t c0, int64_t 
                  (long long)c0, (long long)rows, (long long)cols, (long long)m->prows, (long long)m->pcols);
     mgpi_mat* v = new (std::nothrow) mgpi_mat();
     if (!v) { mgpi_set_error("mgpi_mat_view: out of host memory"); return MGPI_ERR_ALLOC; }
-    *v = *m;
+    v->ctx = m->ctx;
     v->rows = rows;
     v->cols = cols;
     v->prows = rows;   // a view exposes exactly its window
     v->pcols = cols;
+    v->ld = m->ld;
     v->d = m->d + r0 * m->ld + c0;
     v->owns = 0;
+    v->alloc_bytes = 0;
+    // a window of a factor is a factor only when it is the whole (padded) matrix; the parent's cache of inverse
+    // diagonal blocks is never shared (a view that needs one builds and owns its own)
+    v->factored = (m->factored && r0 == 0 && c0 == 0 && rows == m->prows && cols == m->pcols) ? 1 : 0;
+    v->dinv = nullptr;
+    v->dinv_nb = 0;
+    v->dinv_bytes = 0;
     *out = v;
     return 0;
 }
@@ -386,6 +430,7 @@ extern "C" int mgpi_mat_upload(mgpi_mat* m, const double* host, int64_t host_ld)
                                   m->ctx->stream));
     MGPI_HIP_TRY(hipStreamSynchronize(m->ctx->stream));
     m->factored = 0;
+    mat_drop_dinv(m);
     return 0;
 }
 
@@ -408,6 +453,7 @@ extern "C" int mgpi_mat_copy(mgpi_ctx* ctx, const mgpi_mat* src, mgpi_mat* dst) 
     MGPI_HIP_TRY(hipMemcpy2DAsync(dst->d, (size_t)dst->ld * sizeof(double), src->d, (size_t)src->ld * sizeof(double),
                                   (size_t)c * sizeof(double), (size_t)r, hipMemcpyDeviceToDevice, ctx->stream));
     dst->factored = src->factored;
+    mat_drop_dinv(dst);          // inverse blocks of whatever dst held before
     return 0;
 }
 
@@ -466,6 +512,81 @@ extern "C" int mgpi_mat_diag(mgpi_ctx* ctx, const mgpi_mat* m, mgpi_mat* diag) {
     return 0;
 }
 
+__global__ void add_diag_kernel(double* a, int64_t ld, int64_t n, double shift) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i * ld + i] += shift;
+}
+
+extern "C" int mgpi_mat_add_diag(mgpi_ctx* ctx, mgpi_mat* m, double shift) {
+    MGPI_REQUIRE(ctx && m, "mgpi_mat_add_diag: null pointer");
+    MGPI_REQUIRE(m->rows == m->cols, "mgpi_mat_add_diag: matrix is not square");
+    hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((m->rows + 255) / 256)), dim3(256), 0, ctx->stream, m->d, m->ld, m->rows, shift);
+    MGPI_HIP_TRY(hipGetLastError());
+    mgpi_mat_invalidate(m);
+    return 0;
+}
+
+__global__ void fill_diag_kernel(double* a, int64_t ld, int64_t n, double value) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i * ld + i] = value;
+}
+
+// m[i][i] = value for i < min(rows, cols) of the handle (a view addresses a sub-diagonal): the unit diagonal of the
+// padded global indices of a block-cyclic K
+extern "C" int mgpi_mat_fill_diag(mgpi_ctx* ctx, mgpi_mat* m, double value) {
+    MGPI_REQUIRE(ctx && m, "mgpi_mat_fill_diag: null pointer");
+    const int64_t n = m->rows < m->cols ? m->rows : m->cols;
+    hipLaunchKernelGGL(fill_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, m->d, m->ld, n, value);
+    MGPI_HIP_TRY(hipGetLastError());
+    mgpi_mat_invalidate(m);
+    return 0;
+}
+
+__global__ void axpy_kernel(double a, const double* __restrict__ x, double* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = fma(a, x[i], y[i]);
+}
+
+// y += a x for (n x 1) vectors
+extern "C" int mgpi_axpy_dev(mgpi_ctx* ctx, double a, const mgpi_mat* x, mgpi_mat* y) {
+    MGPI_REQUIRE(ctx && x && y, "mgpi_axpy_dev: null pointer");
+    MGPI_REQUIRE(x->ld == 1 && y->ld == 1 && x->rows == y->rows, "mgpi_axpy_dev: x and y must be vectors of one length");
+    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((x->rows + 255) / 256)), dim3(256), 0, ctx->stream, a, x->d, y->d, x->rows);
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void copy_blocks_kernel(const double* __restrict__ src, int64_t lds_, int64_t src_step,
+                                                          double* __restrict__ dst, int64_t ldd, int64_t dst_step, int64_t rows,
+                                                          int64_t cols) {
+    const double* s = src + (int64_t)blockIdx.z * src_step * lds_;
+    double* d = dst + (int64_t)blockIdx.z * dst_step * ldd;
+    const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2, r = blockIdx.y;
+    if (c < cols && r < rows) *reinterpret_cast<double2*>(d + r * ldd + c) = *reinterpret_cast<const double2*>(s + r * lds_ + c);
+}
+
+// block j (j < count) = `rows` full-width rows: dst rows [dst_r0 + j dst_step, ..) <- src rows [src_r0 + j src_step, ..).
+// One launch gathers the blocks a peer wants out of a row panel (they sit lcm(P,Q)/P blocks apart) or scatters them.
+extern "C" int mgpi_copy_blocks_dev(mgpi_ctx* ctx, const mgpi_mat* src, int64_t src_r0, int64_t src_step, mgpi_mat* dst,
+                                    int64_t dst_r0, int64_t dst_step, int64_t rows, int64_t count) {
+    MGPI_REQUIRE(ctx && src && dst, "mgpi_copy_blocks_dev: null pointer");
+    if (count == 0 || rows == 0) return 0;
+    MGPI_REQUIRE(rows > 0 && count > 0 && count < 65536 && rows < 65536 && src_step >= 0 && dst_step >= 0 && src_r0 >= 0 && dst_r0 >= 0,
+                 "mgpi_copy_blocks_dev: bad block description");
+    const int64_t cols = src->pcols < dst->pcols ? src->pcols : dst->pcols;
+    MGPI_REQUIRE(src->pcols == dst->pcols && cols % 2 == 0 && src->ld % 2 == 0 && dst->ld % 2 == 0,
+                 "mgpi_copy_blocks_dev: the matrices must have one (even) width");
+    MGPI_REQUIRE(src_r0 + (count - 1) * src_step + rows <= src->prows && dst_r0 + (count - 1) * dst_step + rows <= dst->prows,
+                 "mgpi_copy_blocks_dev: blocks reach outside the matrices");
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(copy_blocks_kernel, dim3((unsigned)((cols / 2 + 255) / 256), (unsigned)rows, (unsigned)count), dim3(256), 0,
+                       ctx->stream, src->d + src_r0 * src->ld, src->ld, src_step, dst->d + dst_r0 * dst->ld, dst->ld, dst_step, rows,
+                       cols);
+    MGPI_HIP_TRY(hipGetLastError());
+    mgpi_mat_invalidate(dst);
+    return 0;
+}
+
 __global__ void unscale_kernel(double* a, int64_t ld, int64_t n, const double* __restrict__ s) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
     if (j < n) a[i * ld + j] = a[i * ld + j] / (s[i] * s[j]);
@@ -479,6 +600,7 @@ extern "C" int mgpi_mat_unscale(mgpi_ctx* ctx, mgpi_mat* m, const mgpi_mat* s) {
                        m->d, m->ld, m->rows, s->d);
     MGPI_HIP_TRY(hipGetLastError());
     m->factored = 0;
+    mat_drop_dinv(m);
     return 0;
 }
 

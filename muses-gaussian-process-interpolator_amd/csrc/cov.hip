@@ -120,7 +120,7 @@ extern "C" int mgpi_cov_matrix_dev(mgpi_ctx* ctx, const mgpi_mat* X1, const mgpi
     MGPI_TRY(mgpi_make_terms(terms, nterms, (int)X1->cols, &t));
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
     const int sym = (X2 == nullptr);
-    out->factored = 0;
+    mgpi_mat_invalidate(out);
     return mgpi_launch_cov(ctx, t, X1->d, X1->ld, X1->rows, out->prows, Xb->d, Xb->ld, Xb->rows, out->pcols, sym,
                            lower_only, /*pad_identity=*/sym, out->d, out->ld);
 }
@@ -193,7 +193,7 @@ extern "C" int mgpi_cov_block_dev(mgpi_ctx* ctx, const mgpi_mat* X1, int64_t n1_
     mgpi_terms_dev t;
     MGPI_TRY(mgpi_make_terms(terms, nterms, (int)X1->cols, &t));
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
-    out->factored = 0;
+    mgpi_mat_invalidate(out);
     return mgpi_launch_cov(ctx, t, X1->d, X1->ld, n1_valid, out->prows, X2->d, X2->ld, n2_valid, out->pcols, 0, 0, 0,
                            out->d, out->ld);
 }

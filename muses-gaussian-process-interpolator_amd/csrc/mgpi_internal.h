@@ -19,6 +19,7 @@ struct mgpi_prof_slot {
     double flops;       // algorithmic flops of the launches recorded in this slot (set by the launcher)
 };
 
+#define MGPI_PROF_SLOTS 6
 struct mgpi_pool;
 
 struct mgpi_ctx {
@@ -26,13 +27,15 @@ struct mgpi_ctx {
     int nb;                       // outer Cholesky block
     hipStream_t stream;           // where launchers enqueue (the main stream, except during a look-ahead panel)
     hipStream_t stream2;          // high-priority stream of the look-ahead panel factorisation
+    hipEvent_t ev_join;           // mgpi_ctx_wait: "everything queued on this ctx so far"
     hipEvent_t ev_upd, ev_panel;  // main-stream update of a step done / look-ahead stream's panel (block) done
     int no_lookahead;             // MGPI_NO_LOOKAHEAD=1 (developer switch)
     int lean;                     // launch gemms as 64x64 tiles (32 KB LDS, < 104 VGPRs): they can then start next to
                                   // two resident trailing-update workgroups during the look-ahead
     hipEvent_t ev0, ev1;          // tic/toc
     int profile;
-    mgpi_prof_slot* prof;         // [4]: 0 trailing update (lower syrk), 1 panel, 2 whole potrf, 3 next-panel column update
+    mgpi_prof_slot* prof;         // [MGPI_PROF_SLOTS]: 0 trailing update (lower syrk), 1 panel, 2 whole potrf, 3 next-panel
+                                  // column update, 4 big update of the multi-rhs forward solve (variance), 5 fused predict mean
     int* d_info;                  // device: first failing pivot (0 = none)
     double* d_scal;               // device scratch scalars (logdet partials etc.), 4096 doubles
     double* d_diag;               // diag(K) before factoring (pivot threshold), grown on demand
@@ -40,6 +43,7 @@ struct mgpi_ctx {
     double* work;                 // device workspace, grown on demand
     size_t work_bytes;
     mgpi_pool* pool;              // freed matrix buffers awaiting reuse (core.hip)
+    double pivot_tol;             // a pivot must exceed pivot_tol * K_kk(original); 0 = LAPACK's "pivot > 0" rule
 };
 
 struct mgpi_mat {
@@ -89,6 +93,7 @@ void mgpi_set_error(const char* fmt, ...);
 static inline int64_t mgpi_roundup(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 int mgpi_ensure_work(mgpi_ctx* ctx, size_t bytes);
+void mgpi_mat_invalidate(mgpi_mat* m);     // contents change: not a factor any more, cached inverse blocks dropped
 int mgpi_pool_alloc(mgpi_ctx* ctx, size_t bytes, double** out, size_t* got);
 void mgpi_pool_free(mgpi_ctx* ctx, void* ptr, size_t bytes);
 

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(G == 64 ? 64 : 128) void nn_condition_kernel(mgpi_t
                                                            int64_t m, const double* __restrict__ sx,
                                                            const double* __restrict__ sf, const int32_t* __restrict__ idx,
                                                            const int32_t* __restrict__ cnt, int k,
-                                                           double* __restrict__ mean, double* __restrict__ diag) {
+                                                           double* __restrict__ mean, double* __restrict__ diag, double ptol) {
     constexpr int GROUPS = (G == 64 ? 64 : 128) / G;
     constexpr int LD = G + 1;
     __shared__ double A[GROUPS][G * LD];
@@ -246,8 +246,8 @@ __global__ __launch_bounds__(G == 64 ? 64 : 128) void nn_condition_kernel(mgpi_t
         if (live && j < c && r == j) {
             double s = a[j * LD + j];
             for (int q = 0; q < j; ++q) s -= a[j * LD + q] * a[j * LD + q];
-            // same acceptance rule as the dense factorisation (chol.hip): a pivot below 100 eps K_jj is not positive definite
-            a[j * LD + j] = (s > 100.0 * 2.220446049250313e-16 * a0) ? sqrt(s) : __builtin_nan("");
+            // same acceptance rule as the dense factorisation (chol.hip): a pivot not above ptol K_jj is not positive definite
+            a[j * LD + j] = (s > ptol * a0) ? sqrt(s) : __builtin_nan("");
         }
         __syncthreads();
         if (live && j < c && r > j && r < c + 2) {
@@ -303,6 +303,11 @@ extern "C" int mgpi_nn_neighbors(mgpi_ctx* ctx, const double* source_x, const do
     const int within = target_x == nullptr;
     if (within) m = n;
     MGPI_REQUIRE(m >= 1, "mgpi_nn_neighbors: no targets");
+    // every host-side check comes before the first enqueue: an early return must not leave copies from the caller's
+    // buffers in flight
+    for (int64_t j = 1; j < n; ++j)
+        MGPI_REQUIRE(source_rank[j - 1] <= source_rank[j], "mgpi_nn_neighbors: source_rank is not ascending at %lld (sort the "
+                     "reference set first, interpolators.py:645-652)", (long long)j);
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
     const size_t sxb = (size_t)n * d * sizeof(double), srb = (size_t)n * sizeof(double);
     const size_t txb = within ? 0 : (size_t)m * d * sizeof(double), trb = within ? 0 : (size_t)m * sizeof(double);
@@ -322,9 +327,6 @@ extern "C" int mgpi_nn_neighbors(mgpi_ctx* ctx, const double* source_x, const do
         MGPI_HIP_TRY(hipMemcpyAsync(dtx, target_x, txb, hipMemcpyHostToDevice, ctx->stream));
         MGPI_HIP_TRY(hipMemcpyAsync(dtr, target_rank, trb, hipMemcpyHostToDevice, ctx->stream));
     }
-    for (int64_t j = 1; j < n; ++j)
-        MGPI_REQUIRE(source_rank[j - 1] <= source_rank[j], "mgpi_nn_neighbors: source_rank is not ascending at %lld (sort the "
-                     "reference set first, interpolators.py:645-652)", (long long)j);
     const int bound_div = rank_is_sum ? d : 1;     // (rank_t - rank_j)^2 <= bound_div * dist
     if (k <= 8) launch_search<8>(ctx, dsx, dsr, n, d, dtx, dtr, m, within, k, bound_div, didx, dcnt);
     else if (k <= 16) launch_search<16>(ctx, dsx, dsr, n, d, dtx, dtr, m, within, k, bound_div, didx, dcnt);
@@ -380,13 +382,13 @@ extern "C" int mgpi_nn_condition(mgpi_ctx* ctx, const double* target_x, int64_t 
     MGPI_HIP_TRY(hipMemcpyAsync(dcnt, count, cb, hipMemcpyHostToDevice, ctx->stream));
     if (k <= 14) {
         hipLaunchKernelGGL(nn_condition_kernel<16>, dim3((unsigned)((m + 7) / 8)), dim3(128), 0, ctx->stream, t, nkernel, dtx, m,
-                           dsx, dsf, didx, dcnt, k, dmean, ddiag);
+                           dsx, dsf, didx, dcnt, k, dmean, ddiag, ctx->pivot_tol);
     } else if (k <= 30) {
         hipLaunchKernelGGL(nn_condition_kernel<32>, dim3((unsigned)((m + 3) / 4)), dim3(128), 0, ctx->stream, t, nkernel, dtx, m,
-                           dsx, dsf, didx, dcnt, k, dmean, ddiag);
+                           dsx, dsf, didx, dcnt, k, dmean, ddiag, ctx->pivot_tol);
     } else {
         hipLaunchKernelGGL(nn_condition_kernel<64>, dim3((unsigned)m), dim3(64), 0, ctx->stream, t, nkernel, dtx, m,
-                           dsx, dsf, didx, dcnt, k, dmean, ddiag);
+                           dsx, dsf, didx, dcnt, k, dmean, ddiag, ctx->pivot_tol);
     }
     MGPI_HIP_TRY(hipGetLastError());
     MGPI_HIP_TRY(hipMemcpyAsync(out_mean, dmean, ob, hipMemcpyDeviceToHost, ctx->stream));

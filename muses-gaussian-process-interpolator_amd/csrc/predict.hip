@@ -77,6 +77,7 @@ extern "C" int mgpi_predict_mean_dev(mgpi_ctx* ctx, const mgpi_mat* Xs, const mg
         hipLaunchKernelGGL(predict_mean_kernel<DV>, grid, block, 0, ctx->stream, t, Xs->d, Xs->ld, m, X->d, X->ld, n, \
                            alpha->d, chunk_len, ctx->work);                                                      \
         break;
+    mgpi_prof_begin(ctx, 5);
     switch (t.d) {
         MGPI_PM_CASE(1)
         MGPI_PM_CASE(2)
@@ -87,6 +88,8 @@ extern "C" int mgpi_predict_mean_dev(mgpi_ctx* ctx, const mgpi_mat* Xs, const mg
                                alpha->d, chunk_len, ctx->work);
     }
 #undef MGPI_PM_CASE
+    mgpi_prof_end(ctx, 5);
+    mgpi_prof_flops(ctx, 5, (double)m * (double)n);       // kernel evaluations (pairs), not flops
     MGPI_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, ctx->work, m,
                        (int)nchunks, mean->d);
@@ -115,6 +118,32 @@ __global__ __launch_bounds__(256) void colsq_kernel(const double* __restrict__ V
     part[sub][lane] = s;
     __syncthreads();
     if (sub == 0 && c < cols) partial[(int64_t)blockIdx.y * cols + c] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+}
+
+__global__ void sum_chunks_kernel(const double* __restrict__ partial, int64_t n, int nchunks, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * n + i];
+    out[i] = s;
+}
+
+// out[c] = sum over the (padded) rows of V of V[r][c]^2, c < V->cols: the column norms of a local slab of
+// V = L^-1 K*^T in the multi-GPU variance sweep (the single-GPU path fuses this with the prior variance)
+extern "C" int mgpi_colsq_dev(mgpi_ctx* ctx, const mgpi_mat* V, mgpi_mat* out) {
+    MGPI_REQUIRE(ctx && V && out, "mgpi_colsq_dev: null pointer");
+    MGPI_REQUIRE(out->ld == 1 && out->rows == V->cols, "mgpi_colsq_dev: out must be a (cols x 1) vector");
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    const int64_t rows = V->prows, cols = V->cols;
+    const int64_t rchunks = (rows + CN_ROWS - 1) / CN_ROWS;
+    MGPI_REQUIRE(rchunks <= 65535, "mgpi_colsq_dev: too many rows");
+    MGPI_TRY(mgpi_ensure_work(ctx, (size_t)rchunks * cols * sizeof(double)));
+    hipLaunchKernelGGL(colsq_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)rchunks), dim3(256), 0, ctx->stream, V->d, V->ld, rows,
+                       cols, ctx->work);
+    hipLaunchKernelGGL(sum_chunks_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, ctx->stream, ctx->work, cols, (int)rchunks,
+                       out->d);
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 // var[i] = k(xs_i, xs_i) - sum_c partial[c][i]

@@ -303,9 +303,7 @@ class Interpolator(HyperParameterSearch):
         for attempt in range(6):
             _lib.check(ctx.lib.mgpi_mat_copy(ctx.handle, cov.handle, corr.handle))
             if jitter > 0.0:
-                host = corr.to_host()
-                host[np.diag_indices(m)] += jitter
-                corr.upload(host)
+                _lib.check(ctx.lib.mgpi_mat_add_diag(ctx.handle, corr.handle, jitter))
             try:
                 _lib.check(ctx.lib.mgpi_potrf_dev(ctx.handle, corr.handle, None))
                 last = None
