@@ -19,8 +19,12 @@ launches, recorded inside the timed region on the stream the kernel runs on; pea
 fp64 matrix, spec).  cpu_baseline = the numpy oracle (a port of the reference's algorithm) on a bounded
 sample of the same recipe, host cores of this box.
 
-N>1: one process per GPU (torch.distributed.run, backend nccl = RCCL over xGMI).  ONE GP is factored across
-all ranks by the 2-D block-cyclic right-looking Cholesky of muses-gaussian-process-interpolator_amd/distributed.py
+N>1: one process per GPU, RCCL over xGMI through the library's own C-ABI (mgpi_comm_*; no PyTorch anywhere).  The ranks
+are started either by a launcher that exports RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT (the driver's
+`python -m torch.distributed.run ... bench.py`; only its environment is used) or, with `python bench.py --gpus N`
+alone, by this script itself (N child processes, before anything touches the GPU).  Rank 0's RCCL unique id reaches
+the others through a file (mgpi_amd/rendezvous.py).  ONE GP is factored across all ranks by the 2-D block-cyclic
+right-looking Cholesky of muses-gaussian-process-interpolator_amd/distributed.py
 (P x Q = 1x2, 2x2, 2x4; panel broadcasts along process rows and columns, local trailing updates on fp64 MFMA),
 followed by the distributed solve, mean and variance.  Scaling is "weak" in the O(N^3) work: N = 32768 * G^(1/3)
 rounded to the block grid (40960, 52224, 65536 = BASELINE.json configs[3]); value = whole-job algorithmic
@@ -206,14 +210,20 @@ class GpuStep(object):
 
 class DistributedStep(object):
     """one GP across all ranks: block-cyclic build + factor + solve + mean + variance (inputs replicated on the
-    hosts, K / L / V distributed in HBM)"""
+    hosts, K / L / V distributed in HBM; RCCL communicators and every device operation through the C-ABI)"""
 
-    def __init__(self, torch, dist, x, f, xs, ell, host_staged=False):
+    def __init__(self, rank, world, x, f, xs, ell):
         import mgpi_amd as mgpi
-        from mgpi_amd.distributed import DistributedGP, HipTileBackend, ProcessGrid
+        from mgpi_amd.distributed import DistributedGP, HipTileBackend, LocalTransport, ProcessGrid, RcclTransport
+        from mgpi_amd.rendezvous import exchange_unique_id
         self.ctx = mgpi.default_context()
-        self.grid = ProcessGrid(dist, host_staged=host_staged)
-        self.be = HipTileBackend(torch, self.ctx)
+        if world > 1:
+            uid = exchange_unique_id(rank, world, RcclTransport.new_unique_id)
+            self.transport = RcclTransport(self.ctx, uid, rank, world)
+        else:
+            self.transport = LocalTransport()
+        self.grid = ProcessGrid(self.transport)
+        self.be = HipTileBackend(self.ctx)
         k = mgpi.SquaredExponentialKernel(1.0, *ell)
         nug = mgpi.WhiteNoiseKernel(1e-2)
         self.gp = DistributedGP(self.grid, self.be, x, k.terms(), (k + nug).terms(), nb=NB)
@@ -227,6 +237,21 @@ class DistributedStep(object):
         gp.solve(self.f)
         self.mean = gp.mean(self.xs)
         self.var = gp.variance(self.xs)
+
+    def fence(self):
+        """every rank has arrived and its streams are drained (the contract's barrier + device synchronise)"""
+        self.be.sync()
+        self.grid.barrier(self.be)
+        self.be.sync()
+
+    def max_over_ranks(self, value):
+        buf = self.be.alloc(1, 1)
+        self.be.upload(buf, np.array([float(value)]))
+        self.grid.all_reduce(self.be, buf, 'max')
+        return float(self.be.download(buf).reshape(-1)[0])
+
+    def close(self):
+        self.transport.close()
 
 
 def cpu_baseline(seed=7):
@@ -262,6 +287,33 @@ def load_traffic(workload):
         return None
 
 
+def visible_gpus():
+    """number of HIP devices, counted in a CHILD process: the parent of self-launched ranks must never touch the GPU"""
+    import subprocess
+    code = 'import sys; sys.path.insert(0, %r); from mgpi_amd import _lib; print(_lib.device_count())' % ROOT
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    try:
+        return int(out.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        sys.stderr.write(out.stderr[-2000:])
+        return 0
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, before any GPU call in this process"""
+    from mgpi_amd.rendezvous import spawn_ranks
+    have = visible_gpus()
+    if args.gpus > have:
+        sys.stderr.write('bench.py: --gpus %d requested but %d HIP device(s) are visible\n' % (args.gpus, have))
+        return 2
+    codes = spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write('bench.py: ranks failed (rank, exit code): %s\n' % bad)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -271,31 +323,18 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    # developer switch (rehearsal on a one-GPU box): all ranks share GPU 0, gloo with host-staged collectives,
-    # optional small problem MGPI_BENCH_SIDE=16x16x16; the numbers mean nothing, the code path is the N>1 one
-    share_gpu = world > 1 and os.environ.get('MGPI_BENCH_SHARE_GPU') == '1'
-    if share_gpu:
-        local_rank = 0
+    from mgpi_amd.rendezvous import rank_env
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+    rank, local_rank, world = rank_env()
+    if world != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but the launcher started %d rank(s)\n' % (args.gpus, world))
+        sys.exit(2)
     os.environ.setdefault('MGPI_DEVICE', str(local_rank))
 
-    dist = None
-    torch = None
     # developer switch: run the multi-GPU code path on a 1 x 1 grid (one GPU) to exercise its plumbing
     force_dist = world == 1 and os.environ.get('MGPI_BENCH_FORCE_DIST') == '1'
     distributed = world > 1 or force_dist
-    if distributed:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29511')
-        if share_gpu:
-            dist.init_process_group(backend='gloo', rank=rank, world_size=world)
-        else:
-            dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     if not distributed:
         d, m = WORKLOADS[args.workload][1], WORKLOADS[args.workload][2]
@@ -303,24 +342,25 @@ def main():
         step = GpuStep(x, f, xs, ell, sigma, nugget_sigma)
         name, par = args.workload.upper(), 'single GPU'
     else:
-        assert force_dist or world in MULTI, 'supported GPU counts: 1, %s' % sorted(MULTI)
+        if not force_dist and world not in MULTI:
+            sys.stderr.write('bench.py: supported GPU counts: 1, %s\n' % sorted(MULTI))
+            sys.exit(2)
         n_side, d, m, seed = MULTI[2 if force_dist else world]
-        if share_gpu and os.environ.get('MGPI_BENCH_SIDE'):
+        if force_dist and os.environ.get('MGPI_BENCH_SIDE'):
             n_side = tuple(int(v) for v in os.environ['MGPI_BENCH_SIDE'].split('x'))
             d = len(n_side)
         x, f, xs, ell = make_inputs(n_side, m, seed)           # the same seed on every rank: replicated inputs
-        step = DistributedStep(torch, dist, x, f, xs, ell, host_staged=share_gpu)
+        step = DistributedStep(rank, world, x, f, xs, ell)
         name = 'C4' if world == 8 else 'C3 scaled by %d^(1/3)' % world
-        par = '2-D block-cyclic %dx%d, nb=%d, RCCL panel broadcasts' % (step.grid.P, step.grid.Q, NB)
+        par = '2-D block-cyclic %dx%d, nb=%d, RCCL panel broadcasts over xGMI' % (step.grid.P, step.grid.Q, NB)
     n = len(x)
     ctx = step.ctx
 
     def fence():
-        ctx.sync()
         if distributed:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+            step.fence()
+        else:
+            ctx.sync()
 
     for _ in range(args.warmup):
         step.run()
@@ -332,9 +372,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if share_gpu else 'cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = step.max_over_ranks(elapsed)
 
     c5 = (not distributed) and args.workload.startswith('c5')
     slot = 4 if c5 else 0      # the dominant kernel: NN update gemm of the variance solve (C5) / lower syrk of the factorisation
@@ -407,9 +445,10 @@ def main():
                                    'ms_per_step': timed[5][0] / args.steps}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if distributed:
-        dist.destroy_process_group()
+        step.fence()
+        step.close()
 
 
 if __name__ == '__main__':

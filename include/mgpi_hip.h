@@ -99,6 +99,9 @@ int  mgpi_mat_upload(mgpi_mat* m, const double* host, int64_t host_ld);     /* h
 int  mgpi_mat_download(const mgpi_mat* m, double* host, int64_t host_ld);
 int  mgpi_mat_shape(const mgpi_mat* m, int64_t* rows, int64_t* cols, int64_t* ld);
 void* mgpi_mat_devptr(const mgpi_mat* m);                                   /* raw device pointer (double*) */
+/* declare that m holds (factored != 0) or no longer holds a Cholesky factor: for buffers whose content arrived by a
+ * broadcast from the rank that factored it */
+int  mgpi_mat_mark_factored(mgpi_mat* m, int factored);
 /* copy src into dst (same logical shape), e.g. keep K before factoring in place */
 int  mgpi_mat_copy(mgpi_ctx* ctx, const mgpi_mat* src, mgpi_mat* dst);
 /* fill the strict upper triangle from the lower one (square), for downloads of a lower-only build */

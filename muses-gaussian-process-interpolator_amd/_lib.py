@@ -5,7 +5,6 @@ numeric entry point raises.  The library is built in-tree by ``__graft_entry__.b
 ``make -C muses-gaussian-process-interpolator_amd/csrc``.
 """
 import ctypes
-import importlib.util
 import os
 import sys
 import threading
@@ -21,6 +20,7 @@ NN_MAX_NEIGHBORS = 62
 TERM_SE = 0
 TERM_WHITE = 1
 TERM_MATERN = 2
+COMM_ID_BYTES = 128        # MGPI_COMM_ID_BYTES
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int64 = ctypes.c_int64
@@ -66,6 +66,7 @@ _SIGNATURES = {
     'mgpi_mat_download': (ctypes.c_int, [_vp, _vp, c_int64]),
     'mgpi_mat_shape': (ctypes.c_int, [_vp, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
     'mgpi_mat_devptr': (_vp, [_vp]),
+    'mgpi_mat_mark_factored': (ctypes.c_int, [_vp, ctypes.c_int]),
     'mgpi_mat_copy': (ctypes.c_int, [_vp, _vp, _vp]),
     'mgpi_mat_symmetrize': (ctypes.c_int, [_vp, _vp]),
     'mgpi_mat_tril': (ctypes.c_int, [_vp, _vp]),
@@ -128,27 +129,6 @@ _lib = None
 _lib_lock = threading.Lock()
 
 
-def _share_torch_hip_runtime():
-    """One HIP/HSA runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so
-    and ask for them by the un-versioned file name, which the dynamic loader does not match against the
-    ``libamdhip64.so.7`` of /opt/rocm that libmgpi_hip.so would otherwise pull in.  A process that loaded this
-    library first and imports torch later (the multi-GPU driver, a user's own torch code) would then hold two HSA
-    runtimes, and the second one finds no GPU.  So when a torch wheel with a bundled runtime is installed, map ITS
-    runtime first - a dlopen of one file, torch itself is not imported - and libmgpi_hip.so binds to it by soname.
-    MGPI_HIP_RUNTIME=system keeps /opt/rocm's runtime (for processes that never import torch)."""
-    if 'torch' in sys.modules or os.environ.get('MGPI_HIP_RUNTIME', '') == 'system':
-        return
-    try:
-        spec = importlib.util.find_spec('torch')
-    except (ImportError, ValueError):
-        return
-    for root in (spec.submodule_search_locations or []) if spec is not None else []:
-        bundled = os.path.join(root, 'lib', 'libamdhip64.so')
-        if os.path.exists(bundled):
-            ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
-            return
-
-
 def load_library():
     """dlopen libmgpi_hip.so and declare every prototype; raises if the library was not built"""
     global _lib
@@ -157,7 +137,6 @@ def load_library():
             if not os.path.exists(LIB_PATH):
                 raise MgpiError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                                 '(there is no CPU fallback)' % LIB_PATH)
-            _share_torch_hip_runtime()
             lib = ctypes.CDLL(LIB_PATH)
             for name, (restype, argtypes) in _SIGNATURES.items():
                 fn = getattr(lib, name)   # AttributeError if the symbol is missing
@@ -258,6 +237,15 @@ class DeviceMatrix(object):
     @property
     def devptr(self):
         return self.ctx.lib.mgpi_mat_devptr(self.handle)
+
+    def shape3(self):
+        """(rows, cols, row stride) as the library sees this handle"""
+        r, c, ld = c_int64(0), c_int64(0), c_int64(0)
+        check(self.ctx.lib.mgpi_mat_shape(self.handle, ctypes.byref(r), ctypes.byref(c), ctypes.byref(ld)))
+        return r.value, c.value, ld.value
+
+    def mark_factored(self, flag=True):
+        check(self.ctx.lib.mgpi_mat_mark_factored(self.handle, int(bool(flag))))
 
     def free(self):
         if self.handle is not None and self.ctx.handle is not None:

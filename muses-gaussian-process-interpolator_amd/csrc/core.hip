@@ -391,7 +391,7 @@ extern "C" int mgpi_mat_view(const mgpi_mat* m, int64_t r0, int64_t c0, int64_t 
     return 0;
 }
 
-// non-owning handle over caller-provided device memory (e.g. a torch.distributed communication buffer): exactly
+// non-owning handle over caller-provided device memory (e.g. a buffer another library allocated): exactly
 // rows x cols, row stride ld; the caller guarantees the dimensions it later passes to tile kernels are padded
 extern "C" int mgpi_mat_wrap(mgpi_ctx* ctx, void* devptr, int64_t rows, int64_t cols, int64_t ld, int factored, mgpi_mat** out) {
     MGPI_REQUIRE(ctx && devptr && out, "mgpi_mat_wrap: null pointer");
@@ -416,6 +416,14 @@ extern "C" int mgpi_mat_shape(const mgpi_mat* m, int64_t* rows, int64_t* cols, i
     if (rows) *rows = m->rows;
     if (cols) *cols = m->cols;
     if (ld) *ld = m->ld;
+    return 0;
+}
+
+// a buffer that RECEIVED a factored block (broadcast, copy from another process) is a factor too: the solves check
+extern "C" int mgpi_mat_mark_factored(mgpi_mat* m, int factored) {
+    MGPI_REQUIRE(m != nullptr, "mgpi_mat_mark_factored: null matrix");
+    if (!factored) mgpi_mat_invalidate(m);
+    else m->factored = 1;
     return 0;
 }
 

@@ -179,7 +179,13 @@ extern "C" int mgpi_predict_var_dev(mgpi_ctx* ctx, const mgpi_mat* Xs, const mgp
     MGPI_TRY(mgpi_make_terms(terms, nterms, (int)X->cols, &t));
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
     const int64_t m = Xs->rows, n = X->rows, pn = L->prows;
-    if (m_slab <= 0) m_slab = 8192;
+    if (m_slab <= 0) {
+        // default: a V slab of ~4 GB (288 GB of HBM: wide slabs mean fewer, larger update gemms - at N = 13160 a slab of
+        // 8192 queries gives 64 x 103 tiles per update, 13 rounds of the chip with a 4 % tail), between 8192 and 65536 queries
+        m_slab = (int64_t)(((size_t)4 << 30) / ((size_t)pn * sizeof(double)));
+        if (m_slab < 8192) m_slab = 8192;
+        if (m_slab > 65536) m_slab = 65536;
+    }
     // keep the V slab under ~24 GB
     while (m_slab > 128 && (size_t)pn * (size_t)m_slab * sizeof(double) > ((size_t)24 << 30)) m_slab /= 2;
     m_slab = mgpi_roundup(m_slab, MGPI_TILE);

@@ -1,6 +1,14 @@
-"""CPU tile backend for the multi-GPU driver's gloo tests: the same interface as HipTileBackend, every tile
-operation done by numpy/scipy and the oracle's kernel evaluation.  TEST INFRASTRUCTURE ONLY - it lets the
-block-cyclic schedule (ownership, broadcast order, index bookkeeping) run at world size 2 and 4 without a GPU."""
+"""Test implementations of the two interfaces the multi-GPU schedule (mgpi_amd/distributed.py) is written against.
+TEST INFRASTRUCTURE ONLY - the product never constructs them.
+
+  NumpyTileBackend   every tile operation by numpy/scipy and the oracle's kernel evaluation, buffers = numpy arrays:
+                     the block-cyclic schedule (ownership, broadcast order, index bookkeeping) runs at world size
+                     2..8 without a GPU
+  GlooTransport      the collectives over torch.distributed's gloo backend, on numpy buffers
+  HostStagedTransport  GlooTransport under the HIP tile backend: device buffers cross through host copies, so that
+                     several ranks can SHARE one GPU (RCCL refuses two ranks on one device) - the rehearsal of the
+                     real multi-rank tile distribution on a one-GPU box
+"""
 import numpy as np
 from scipy.linalg import solve_triangular
 
@@ -12,100 +20,210 @@ def _terms(terms):
 
 
 class NumpyTileBackend(object):
-    def __init__(self, torch):
-        self.torch = torch
+    def __init__(self):
+        self._pivot, self._logdiag = 0, 0.0
 
-    def zeros(self, rows, cols=None):
-        shape = (rows,) if cols is None else (rows, cols)
-        return self.torch.zeros(shape, dtype=self.torch.float64)
-
-    def empty(self, rows, cols=None):
-        t = self.zeros(rows, cols)
-        t.fill_(float('nan'))          # poison: an element that is read before being written shows up in the results
-        return t
-
-    def from_numpy(self, a):
-        return self.torch.from_numpy(np.array(a, dtype=np.float64, copy=True))
-
-    def to_numpy(self, t):
-        return t.numpy().copy()
-
-    def fence(self):
-        pass
-
-    # the look-ahead's second stream: on the CPU everything simply runs in program order
+    # -- streams: on the CPU everything runs in program order
     def side_backend(self):
         return self
 
-    def record(self):
-        return None
-
-    def on_side(self, after):
-        import contextlib
-        return contextlib.nullcontext()
-
-    def join_side(self):
+    def wait(self, other):
         pass
 
-    def cov(self, x_rows, x_cols, terms, out, n_rows_valid, n_cols_valid):
-        out.zero_()
-        if n_rows_valid and n_cols_valid:
-            out.numpy()[:n_rows_valid, :n_cols_valid] = oracle.x2cov_chunked(_terms(terms), x_rows[:n_rows_valid],
-                                                                             x_cols[:n_cols_valid])
+    def sync(self):
+        pass
 
-    def potrf(self, block):
-        a = block.numpy()
-        sym = np.tril(a) + np.tril(a, -1).T
+    # -- memory
+    def alloc(self, rows, cols=1, zero=True):
+        a = np.zeros((rows, cols))
+        if not zero:
+            a.fill(np.nan)         # poison: an element that is read before being written shows up in the results
+        return a
+
+    def window(self, buf, r0, rows, c0=0, cols=None):
+        cols = buf.shape[1] if cols is None else cols
+        v = buf[r0:r0 + rows, c0:c0 + cols]
+        assert v.shape == (rows, cols), 'window (%d,%d)+(%d x %d) outside %s' % (r0, c0, rows, cols, buf.shape)
+        return v
+
+    def copy(self, dst, src):
+        assert dst.shape == src.shape, (dst.shape, src.shape)
+        dst[...] = src
+
+    def copy_blocks(self, dst, dst_r0, dst_step, src, src_r0, src_step, rows, count):
+        for j in range(count):
+            d = dst[dst_r0 + j * dst_step:dst_r0 + j * dst_step + rows]
+            s = src[src_r0 + j * src_step:src_r0 + j * src_step + rows]
+            assert d.shape == s.shape and d.shape[0] == rows, (d.shape, s.shape, rows)
+            d[...] = s
+
+    def fill_diag(self, buf, value):
+        n = min(buf.shape)
+        buf[np.arange(n), np.arange(n)] = value
+
+    def upload(self, buf, array):
+        buf[...] = np.asarray(array, dtype=float).reshape(buf.shape)
+
+    def download(self, buf):
+        return np.array(buf, copy=True)
+
+    # -- tile kernels
+    def cov(self, x_rows, x_cols, terms, out, n_rows_valid, n_cols_valid):
+        out[...] = 0.0
+        if n_rows_valid and n_cols_valid:
+            out[:n_rows_valid, :n_cols_valid] = oracle.x2cov_chunked(_terms(terms), x_rows[:n_rows_valid], x_cols[:n_cols_valid])
+
+    def status_reset(self):
+        self._pivot, self._logdiag = 0, 0.0
+
+    def potrf_block(self, block, pivot_base):
+        sym = np.tril(block) + np.tril(block, -1).T
         try:
             L = np.linalg.cholesky(sym)
         except np.linalg.LinAlgError:
-            return 1, 0.0
-        a[:] = L
-        return 0, float(np.sum(np.log(np.diag(L))))
+            cand = pivot_base + 1
+            self._pivot = cand if self._pivot == 0 else min(self._pivot, cand)
+            return
+        block[...] = L
+        self._logdiag += float(np.sum(np.log(np.diag(L))))
+
+    def status_read(self):
+        return self._pivot, self._logdiag
 
     def trsm_right(self, lkk, rows):
-        r = rows.numpy()
-        r[:] = solve_triangular(np.tril(lkk.numpy()), r.T, lower=True).T
-
-    def gemm_nt(self, c, a, b):
-        c.numpy()[:] -= a.numpy() @ b.numpy().T
+        rows[...] = solve_triangular(np.tril(lkk), rows.T, lower=True).T
 
     def gemm_nt_stair(self, c, a, b, P, p, Q, q, bi0, bj0, nb):
-        cn, an, bn = c.numpy(), a.numpy(), b.numpy()
-        for bj in range(cn.shape[1] // nb):
+        for bj in range(c.shape[1] // nb):
             J = q + Q * (bj0 + bj)
-            for bi in range(cn.shape[0] // nb):
+            for bi in range(c.shape[0] // nb):
                 I = p + P * (bi0 + bi)
                 if I >= J:
-                    cn[bi * nb:(bi + 1) * nb, bj * nb:(bj + 1) * nb] -= an[bi * nb:(bi + 1) * nb] @ bn[bj * nb:(bj + 1) * nb].T
+                    c[bi * nb:(bi + 1) * nb, bj * nb:(bj + 1) * nb] -= a[bi * nb:(bi + 1) * nb] @ b[bj * nb:(bj + 1) * nb].T
 
     def gemm_nn(self, c, a, b):
-        c.numpy()[:] -= a.numpy() @ b.numpy()
+        c -= a @ b
 
     def trtri_neg(self, a_local, r0, c0, row_step, col_step, w, batch, out):
-        a, o = a_local.numpy(), out.numpy()
-        o[:batch * w, :w] = 0.0
+        out[:batch * w, :w] = 0.0
         for j in range(batch):
-            blk = np.tril(a[r0 + j * row_step:r0 + j * row_step + w, c0 + j * col_step:c0 + j * col_step + w])
-            o[j * w:(j + 1) * w, :w] = -solve_triangular(blk, np.eye(w), lower=True)
+            blk = np.tril(a_local[r0 + j * row_step:r0 + j * row_step + w, c0 + j * col_step:c0 + j * col_step + w])
+            out[j * w:(j + 1) * w, :w] = -solve_triangular(blk, np.eye(w), lower=True)
 
     def trsm_left(self, lkk, rhs):
-        r = rhs.numpy()
-        r[:] = solve_triangular(np.tril(lkk.numpy()), r, lower=True)
+        rhs[...] = solve_triangular(np.tril(lkk), rhs, lower=True)
 
     def trsv(self, lkk, vec, trans):
-        v = vec.numpy()
-        v[:] = solve_triangular(np.tril(lkk.numpy()), v, lower=True, trans='T' if trans else 'N')
+        vec[...] = solve_triangular(np.tril(lkk), vec, lower=True, trans='T' if trans else 'N')
 
     def gemv(self, a, x, y, trans):
-        y.numpy()[:] -= (a.numpy().T if trans else a.numpy()) @ x.numpy()
+        y -= (a.T if trans else a) @ x
+
+    def axpy(self, a, x, y):
+        y += a * x
+
+    def colsq(self, v, out):
+        out[:, 0] = (v * v).sum(axis=0)[:out.shape[0]]
 
     def predict_mean(self, xs, x, terms, alpha):
         return oracle.x2cov_chunked(_terms(terms), xs, x) @ alpha
 
-    def colsq(self, v):
-        a = v.numpy()
-        return (a * a).sum(axis=0)
-
     def prior_diag(self, xs, terms):
         return oracle.paired_cov(_terms(terms), xs, xs)
+
+
+class GlooGroup(object):
+    """a torch.distributed process group; member index <-> global rank through `ranks`.  Buffers are numpy arrays."""
+
+    def __init__(self, torch, dist, group, ranks):
+        self.torch, self.dist, self.group, self.ranks = torch, dist, group, list(ranks)
+        self.size = len(self.ranks)
+
+    def _t(self, buf):
+        assert buf.flags['C_CONTIGUOUS'], 'a communication buffer must be contiguous'
+        return self.torch.from_numpy(buf)
+
+    def bcast(self, be, buf, root):
+        self.dist.broadcast(self._t(buf), src=self.ranks[root], group=self.group)
+
+    def reduce_sum(self, be, buf, root):
+        # gloo's reduce leaves garbage in the non-root buffers; the schedule does not read them afterwards
+        self.dist.reduce(self._t(buf), dst=self.ranks[root], op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def allreduce(self, be, buf, op='sum'):
+        red = self.dist.ReduceOp.SUM if op == 'sum' else self.dist.ReduceOp.MAX
+        self.dist.all_reduce(self._t(buf), op=red, group=self.group)
+
+    def allgather(self, be, send, recv):
+        parts = [self.torch.empty(send.shape, dtype=self.torch.float64) for _ in range(self.size)]
+        self.dist.all_gather(parts, self._t(np.ascontiguousarray(send)), group=self.group)
+        recv[...] = np.concatenate([p.numpy() for p in parts]).reshape(recv.shape)
+
+    def barrier(self, be):
+        self.dist.barrier(group=self.group)
+
+
+class GlooTransport(object):
+    def __init__(self, torch, dist):
+        self.torch, self.dist = torch, dist
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+
+    def world_group(self):
+        return GlooGroup(self.torch, self.dist, None, range(self.world))
+
+    def make_groups(self, rank_lists):
+        mine = None
+        for ranks in rank_lists:           # every rank creates every group, in the same order
+            grp = self.dist.new_group(list(ranks))
+            if self.rank in ranks:
+                mine = GlooGroup(self.torch, self.dist, grp, ranks)
+        assert mine is not None
+        return mine
+
+    def close(self):
+        pass
+
+
+class _StagedGroup(object):
+    """device buffer -> host copy -> gloo collective -> device buffer"""
+
+    def __init__(self, inner):
+        self.inner, self.size = inner, inner.size
+
+    def _staged(self, be, buf, fn):
+        host = be.download(buf)            # waits for the producing kernels
+        fn(host)
+        be.upload(buf, host)
+
+    def bcast(self, be, buf, root):
+        self._staged(be, buf, lambda h: self.inner.bcast(be, h, root))
+
+    def reduce_sum(self, be, buf, root):
+        self._staged(be, buf, lambda h: self.inner.reduce_sum(be, h, root))
+
+    def allreduce(self, be, buf, op='sum'):
+        self._staged(be, buf, lambda h: self.inner.allreduce(be, h, op))
+
+    def allgather(self, be, send, recv):
+        out = np.empty((recv.rows, recv.cols))
+        self.inner.allgather(be, be.download(send), out)
+        be.upload(recv, out)
+
+    def barrier(self, be):
+        be.sync()
+        self.inner.barrier(be)
+
+
+class HostStagedTransport(object):
+    def __init__(self, inner):
+        self.inner = inner
+        self.world, self.rank = inner.world, inner.rank
+
+    def world_group(self):
+        return _StagedGroup(self.inner.world_group())
+
+    def make_groups(self, rank_lists):
+        return _StagedGroup(self.inner.make_groups(rank_lists))
+
+    def close(self):
+        pass

@@ -39,3 +39,54 @@ def test_inputs_are_seeded_and_shaped():
     assert x.shape == (64, 3) and f.shape == (64,) and xs.shape == (10, 3) and len(ell) == 3
     assert (x == x2).all() and (f == f2).all() and (xs == xs2).all()
     assert ell == (0.5, 0.5, 0.5)
+
+
+def test_gpus_flag_is_honoured_without_a_launcher():
+    """`python bench.py --gpus N` with no launcher starts N ranks itself - or says why it cannot.  On this CPU-only
+    box the device count (taken in a child process; the parent never touches the GPU) is 0, so the run must exit
+    non-zero with a message instead of silently benchmarking one GPU."""
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(bench.__file__), 'bench.py'), '--gpus', '2', '--steps', '1'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    if bench.visible_gpus() >= 2:
+        assert out.returncode == 0 and '"n_gpus": 2' in out.stdout, out.stderr[-2000:]
+    else:
+        assert out.returncode == 2 and '--gpus 2 requested' in out.stderr, (out.returncode, out.stderr[-2000:])
+    # a launcher whose world size disagrees with --gpus is refused as well
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(bench.__file__), 'bench.py'), '--gpus', '4', '--steps', '1'],
+                         env=dict(env, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0'), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 2 and 'launcher started 2' in out.stderr
+
+
+def test_unique_id_rendezvous_between_processes(tmp_path):
+    """rank 0's blob reaches every other rank through the rendezvous file (three real processes, no GPU)"""
+    import os
+    import subprocess
+    import sys
+    from mgpi_amd import rendezvous
+    script = tmp_path / 'rank.py'
+    script.write_text(
+        'import os, sys\n'
+        'sys.path.insert(0, %r)\n'
+        'from mgpi_amd.rendezvous import exchange_unique_id, rank_env\n'
+        'rank, local, world = rank_env()\n'
+        'blob = exchange_unique_id(rank, world, lambda: bytes(range(128)), timeout=60)\n'
+        'assert blob == bytes(range(128)) and world == 3 and local == rank\n'
+        'open(os.path.join(%r, "ok%%d" %% rank), "w").close()\n'
+        'import time\n'
+        'while rank == 0 and not all(os.path.exists(os.path.join(%r, "ok%%d" %% r)) for r in range(world)): time.sleep(0.01)\n' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path), str(tmp_path)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MGPI_RENDEZVOUS')}
+    codes = rendezvous.spawn_ranks([str(script)], 3, env=env, timeout=120)
+    assert codes == [0, 0, 0]
+    assert all((tmp_path / ('ok%d' % r)).exists() for r in range(3))
+    # the launcher-less naming (parent pid + master port): two children of THIS process agree on it
+    script2 = tmp_path / 'rank2.py'
+    for r in range(3):
+        (tmp_path / ('ok%d' % r)).unlink()
+    script2.write_text(script.read_text().replace('world == 3', 'world == 2'))
+    procs = [subprocess.Popen([sys.executable, str(script2)], env=dict(env, RANK=str(r), WORLD_SIZE='2', MASTER_PORT='45678'))
+             for r in (1, 0)]
+    assert [p.wait(timeout=120) for p in procs] == [0, 0]

@@ -30,7 +30,7 @@ def _worker(rank, world, P, Q, n, d, m, nb, port, seed, lookahead='1'):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from mgpi_amd.distributed import DistributedGP, ProcessGrid
-        from dist_cpu_backend import NumpyTileBackend
+        from dist_cpu_backend import GlooTransport, NumpyTileBackend
         from oracle import mgpi_oracle as oracle
 
         rng = np.random.default_rng(seed)
@@ -41,9 +41,9 @@ def _worker(rank, world, P, Q, n, d, m, nb, port, seed, lookahead='1'):
         ell = tuple(np.full(d, 0.3))
         kernel = [(0, 1.1, ell), (1, 0.02, ())]        # white noise inside the kernel too
         nugget = [(1, 0.1, ())]
-        grid = ProcessGrid(dist, P, Q)
+        grid = ProcessGrid(GlooTransport(torch, dist), P, Q)
         assert (grid.p, grid.q) == divmod(rank, Q)
-        gp = DistributedGP(grid, NumpyTileBackend(torch), x, kernel, kernel + nugget, nb=nb)
+        gp = DistributedGP(grid, NumpyTileBackend(), x, kernel, kernel + nugget, nb=nb)
         gp.build()
         logdet = gp.factor()
         alpha = gp.solve(f)
@@ -68,7 +68,7 @@ def _worker(rank, world, P, Q, n, d, m, nb, port, seed, lookahead='1'):
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         assert torch.equal(lo, hi), 'ranks disagree'
         # a non positive definite matrix is reported on every rank with the same pivot
-        bad = DistributedGP(grid, NumpyTileBackend(torch), np.vstack([x[:5], x[:5]]), [(0, 1.0, ell)], [(0, 1.0, ell)], nb=nb)
+        bad = DistributedGP(grid, NumpyTileBackend(), np.vstack([x[:5], x[:5]]), [(0, 1.0, ell)], [(0, 1.0, ell)], nb=nb)
         bad.build()
         try:
             bad.factor()

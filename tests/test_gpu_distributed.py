@@ -1,9 +1,18 @@
-"""The multi-GPU driver with the HIP tile backend on ONE GPU (1 x 1 grid): every tile operation goes through
-the wrapped-view C-ABI entry points the N>1 path uses (mgpi_mat_wrap, mgpi_cov_block_dev, mgpi_trsm_right_dev,
-mgpi_gemm_nt/nn_dev, mgpi_trsv_dev, mgpi_gemv_dev); only the collectives are no-ops.  The communication
-schedule itself is covered by tests/test_distributed_cpu.py (gloo, world size 2 and 4)."""
+"""The multi-GPU driver with the HIP tile backend, as far as ONE GPU can take it (run with -m gpu):
+
+  * 1 x 1 grid, LocalTransport: every tile operation goes through the windowed C-ABI entry points the N>1 path uses
+    (mgpi_mat_view, mgpi_cov_block_dev, mgpi_potrf_enqueue_dev, mgpi_trsm_right_dev, mgpi_gemm_nt_stair/nn_dev,
+    mgpi_copy_blocks_dev, mgpi_trsv_dev, mgpi_gemv_dev, mgpi_axpy_dev, mgpi_colsq_dev);
+  * RCCL through the C-ABI (mgpi_comm_*): communicator creation, row / column splits and every collective of the
+    schedule on a one-rank world - and on a two-rank world when the box has two GPUs;
+  * P*Q ranks sharing GPU 0 with host-staged gloo collectives (tests/dist_gpu_worker.py): the real multi-rank tile
+    distribution with the HIP kernels.
+The communication schedule itself is also covered on the CPU by tests/test_distributed_cpu.py (gloo, world size 2..8).
+"""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -14,26 +23,12 @@ from oracle import mgpi_oracle as oracle
 
 pytestmark = pytest.mark.gpu
 
-
-@pytest.fixture(scope='module')
-def dist1():
-    import torch
-    import torch.distributed as dist
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=0, world_size=1)
-    yield torch, dist
-    dist.destroy_process_group()
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize('n,m,nb', [(1500, 200, 512), (700, 130, 128), (2048, 64, 512)])
-def test_hip_tile_backend_single_rank(dist1, n, m, nb):
-    torch, dist = dist1
-    from mgpi_amd.distributed import DistributedGP, HipTileBackend, ProcessGrid
+@pytest.mark.parametrize('n,m,nb,lookahead', [(1500, 200, 512, True), (700, 130, 128, True), (2048, 64, 512, False)])
+def test_hip_tile_backend_single_rank(n, m, nb, lookahead):
+    from mgpi_amd.distributed import DistributedGP, HipTileBackend, LocalTransport, ProcessGrid
     rng = np.random.default_rng(n)
     x = rng.random((n, 3))
     f = np.sin(3 * x[:, 0]) * np.cos(2 * x[:, 1]) + x[:, 2]
@@ -42,9 +37,9 @@ def test_hip_tile_backend_single_rank(dist1, n, m, nb):
     k = mgpi.SquaredExponentialKernel(1.0, *ell)
     nug = mgpi.WhiteNoiseKernel(1e-2)
     ctx = mgpi.Context(device=0, nb=nb)
-    gp = DistributedGP(ProcessGrid(dist, 1, 1), HipTileBackend(torch, ctx), x, k.terms(), (k + nug).terms(), nb=nb)
+    gp = DistributedGP(ProcessGrid(LocalTransport(), 1, 1), HipTileBackend(ctx), x, k.terms(), (k + nug).terms(), nb=nb)
     gp.build()
-    logdet = gp.factor()
+    logdet = gp.factor(lookahead=lookahead)
     alpha = gp.solve(f)
     mean = gp.mean(xs)
     var = gp.variance(xs)
@@ -61,45 +56,49 @@ def test_hip_tile_backend_single_rank(dist1, n, m, nb):
     it = mgpi.Interpolator(k, nugget=nug)
     m1, v1 = it.condition_diag(xs, x, f)
     assert relmax(mean, m1) < 1e-11 and np.max(np.abs(var - v1)) < 1e-11
+    # a singular matrix: the failing pivot travels through the device-resident status
+    bad = DistributedGP(ProcessGrid(LocalTransport(), 1, 1), HipTileBackend(ctx), np.vstack([x[:n - 1], x[:1]]), k.terms(),
+                        k.terms(), nb=nb)
+    bad.build()
+    with pytest.raises(np.linalg.LinAlgError) as err:
+        bad.factor(lookahead=lookahead)
+    assert err.value.pivot == n
 
 
-def test_nccl_collectives_on_device_buffers():
-    """RCCL path on one rank: the driver's collectives (broadcast / reduce inside row and column groups, world
-    broadcast) are issued for real on device buffers through the nccl backend, on the stream shared with the
-    tile kernels.  Run in a subprocess because a process holds one default process group."""
-    import subprocess
-    import sys
-    code = r'''
-import os, sys, numpy as np
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
-import torch, torch.distributed as dist
-os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[1]
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-import mgpi_amd as mgpi
-from mgpi_amd.distributed import DistributedGP, HipTileBackend, ProcessGrid
-from oracle import mgpi_oracle as oracle
-rng = np.random.default_rng(0)
-n, m = 1100, 70
-x = rng.random((n, 2)); f = np.sin(4 * x[:, 0]) + x[:, 1]; xs = rng.random((m, 2))
-k = mgpi.SquaredExponentialKernel(1.0, 0.1, 0.1); nug = mgpi.WhiteNoiseKernel(1e-2)
-ctx = mgpi.Context(device=0, nb=256)
-gp = DistributedGP(ProcessGrid(dist, 1, 1, always_communicate=True), HipTileBackend(torch, ctx), x, k.terms(), (k + nug).terms(), nb=256)
-gp.build(); gp.factor(); alpha = gp.solve(f); mean = gp.mean(xs); var = gp.variance(xs)
-K = oracle.x2cov_chunked([oracle.term_se(1.0, 0.1, 0.1), oracle.term_white(1e-2)], x, x)
-L = np.linalg.cholesky(K); ref = oracle.solve_cholesky(L, f)
-assert np.max(np.abs(alpha - ref)) < 1e-9 * np.max(np.abs(ref))
-assert np.max(np.abs(mean - oracle.x2cov_chunked([oracle.term_se(1.0, 0.1, 0.1)], xs, x) @ ref)) < 1e-10
-dist.destroy_process_group()
-print("NCCL-OK")
-'''
+def _run_ranks(world, args, timeout=600):
+    """start `world` ranks of tests/dist_gpu_worker.py and return their outputs"""
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    out = subprocess.run([sys.executable, '-c', code, str(port)], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                         capture_output=True, text=True, timeout=300)
-    assert 'NCCL-OK' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    worker = os.path.join(HERE, 'dist_gpu_worker.py')
+    rdzv = os.path.join('/tmp', 'mgpi_test_rdzv_%d_%d' % (os.getpid(), port))
+    env = dict(os.environ, MGPI_RENDEZVOUS=rdzv)
+    procs = [subprocess.Popen([sys.executable, worker] + [str(v) for v in (r, world, port) + tuple(args)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    try:
+        for pr in procs:
+            outs.append(pr.communicate(timeout=timeout)[0])
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        if os.path.exists(rdzv):
+            os.remove(rdzv)
+    for r, (pr, out) in enumerate(zip(procs, outs)):
+        assert pr.returncode == 0 and 'RANK-%d-OK' % r in out, 'rank %d:\n%s' % (r, out[-3000:])
+
+
+def test_rccl_collectives_through_the_c_abi():
+    """mgpi_comm_create / split / bcast / reduce_sum / allreduce / allgather / barrier on device buffers, on the ctx
+    stream: the whole GP on a one-rank world with every collective issued, plus direct checks of each collective; on a
+    box with two or more GPUs the same on a 1 x 2 grid with one rank per GPU (RCCL over xGMI)."""
+    _run_ranks(1, ('rccl', 1, 1, 1100, 70, 256, 2, 1))
+    from mgpi_amd import _lib
+    if _lib.device_count() >= 2:
+        _run_ranks(2, ('rccl', 1, 2, 2300, 200, 256, 3, 1))
+        _run_ranks(2, ('rccl', 2, 1, 1500, 100, 128, 2, 0))
 
 
 @pytest.mark.parametrize('P,Q,n,m,nb,d,lookahead', [(1, 2, 1500, 130, 256, 3, 1), (2, 1, 1100, 70, 128, 2, 1),
@@ -108,23 +107,4 @@ def test_hip_tile_backend_multi_rank_on_one_gpu(P, Q, n, m, nb, d, lookahead):
     """P*Q ranks share GPU 0 (gloo, host-staged collectives - tests/dist_gpu_worker.py): the multi-rank tile
     distribution with the HIP kernels, which a one-GPU box cannot otherwise run.  At most 4 ranks + this process
     touch the card (the box allows 6)."""
-    import subprocess
-    import sys
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    world = P * Q
-    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dist_gpu_worker.py')
-    procs = [subprocess.Popen([sys.executable, worker] + [str(v) for v in (r, world, port, P, Q, n, m, nb, d, lookahead)],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
-    outs = []
-    try:
-        for pr in procs:
-            outs.append(pr.communicate(timeout=300)[0])
-    finally:
-        for pr in procs:
-            if pr.poll() is None:
-                pr.kill()
-    for r, (pr, out) in enumerate(zip(procs, outs)):
-        assert pr.returncode == 0 and 'RANK-%d-OK' % r in out, 'rank %d:\n%s' % (r, out[-3000:])
+    _run_ranks(P * Q, ('staged', P, Q, n, m, nb, d, lookahead))

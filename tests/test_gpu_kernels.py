@@ -233,7 +233,7 @@ def test_trtri_neg_strided_batch(ctx, w, batch, row_step, col_step):
 
 
 @pytest.mark.parametrize('env', [{'MGPI_GEMM_PIPE': '0'}, {'MGPI_GEMM_PIPE': '0', 'MGPI_GEMM_GLDS': '0'}, {'MGPI_GEMM_PP': '1'},
-                                 {'MGPI_NO_LOOKAHEAD': '1'}, {'MGPI_POOL_MB': '0'}, {'MGPI_HIP_RUNTIME': 'system'},
+                                 {'MGPI_NO_LOOKAHEAD': '1'}, {'MGPI_POOL_MB': '0'},
                                  {'MGPI_SUPER_PANELS': '1', 'MGPI_SUPER_MIN': '512'}, {'MGPI_SUPER_PANELS': '2', 'MGPI_SUPER_MIN': '512'},
                                  {'MGPI_SUPER_PANELS': '4', 'MGPI_SUPER_MIN': '512'}, {'MGPI_VAR_DINV': '0'}, {'MGPI_PANEL_RIGHT': '0'}, {'MGPI_PANEL_FUSE': '0'},
                                  {'MGPI_PANEL_FUSE_ROWS': '1000000', 'MGPI_SUPER_MIN': '512'},

@@ -53,6 +53,18 @@ def test_product_never_imports_the_oracle():
                 assert 'mgpi_oracle' not in text and 'from oracle' not in text and 'import oracle' not in text, name
 
 
+def test_product_is_free_of_pytorch():
+    """north_star: "no PyTorch".  Device memory, streams and RCCL all go through the C-ABI; nothing under the package -
+    nor bench.py - imports or names torch (the gloo CPU tests inject their own transport from tests/)."""
+    pkg = os.path.join(ROOT, 'muses-gaussian-process-interpolator_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for name in files:
+            if name.endswith(('.py', '.hip', '.h')):
+                assert 'torch' not in open(os.path.join(dirpath, name)).read().lower(), name
+    bench_src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert 'import torch' not in bench_src and 'torch.cuda' not in bench_src
+
+
 # ---- parameter containers: behaviour of mgpi/kernels.py:24-118,191-285 -----------------------------------
 
 def test_parameter_names_and_values():
