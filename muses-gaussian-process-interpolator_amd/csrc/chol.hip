@@ -11,75 +11,7 @@
 #include <math.h>
 #include <vector>
 
-// The latency-bound kernels of the panel chain share their SIMDs with two waves of the trailing update during the
-// look-ahead.  Their own instruction streams are short dependent chains; raising the wave priority lets the SIMD's
-// arbiter issue them as soon as they are ready instead of round-robin behind MFMA issues.
-#define MGPI_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
-
-#define IB MGPI_IB
-
-// ---- 64x64 diagonal block: unblocked Cholesky in LDS, one workgroup ------------------------------------
-// reads only the lower triangle; writes L (lower) and zeros the strict upper part of the block.
-// info: first failing pivot (1-based, global index pivot_base + k + 1), written with atomicCAS-min semantics.
-// A pivot fails when it is not above MGPI_PIVOT_TOL * K_kk(original): zero/negative pivots (LAPACK's test) and
-// pivots that are pure rounding noise.  The second part is what makes an exactly singular K - duplicated source
-// rows under the exact-equality white noise, where the reference's inv raises LinAlgError - fail here too
-// instead of returning garbage.
-// The threshold is ctx->pivot_tol (default 100 eps; mgpi_ctx_set_pivot_tol / MGPI_PIVOT_TOL; 0 = LAPACK's rule alone).
-
-// broadcast lane `l` (compile-time constant after unrolling) of a double to the whole wave: two v_readlane_b32
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-
-template <int SRC>
-__device__ __forceinline__ double potf2_quad_bcast(double v) {
-    constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);   // quad_perm: every lane reads quad lane SRC
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-
-template <int K>
-struct potf2_steps {
-    static __device__ __forceinline__ void run(double (&a)[16], double (*col)[IB], const double* dtol, int r, int q, int& bad) {
-        constexpr int QK = K / 16, KL = K % 16;
-        if (q == QK) col[K & 1][r] = (r >= K) ? a[KL] : 0.0;      // rows above k contribute nothing
-        __syncthreads();
-        const double d = col[K & 1][K];
-        const bool ok = d > dtol[K];                                // false for NaN too
-        if (!ok && bad == 0) bad = K + 1;
-        // Two reciprocals of the pivot, deliberately separate.  A dependent fp64 op costs 32 cycles, so what sets the time
-        // of this kernel is the chain pivot -> multiplier -> update -> next pivot, not the arithmetic volume:
-        //  * ON the chain, the multiplier a_r[k] / pivot uses 1/pivot from v_rcp_f64 + ONE fma-form Newton step
-        //    (estimate ~2^-27 -> ~2^-53: two dependent ops);
-        //  * OFF the chain, 1/sqrt(pivot) (estimate + two Newton steps, eight dependent ops) only feeds the values that
-        //    are STORED as the factor - nothing later in the chain reads them - so it runs in the shadow of the update.
-        // (The first version derived the multiplier from 1/sqrt(pivot) squared and had all ten ops on the chain.)
-        const double dd = ok ? d : 1.0;
-        double p = __builtin_amdgcn_rcp(dd);
-        p = fma(p, fma(-dd, p, 1.0), p);
-        double y = __builtin_amdgcn_rsq(dd);
-        y = fma(y * 0.5, fma(-dd * y, y, 1.0), y);
-        y = fma(y * 0.5, fma(-dd * y, y, 1.0), y);
-        double c[16];
-#pragma unroll
-        for (int j = 0; j < 16; j += 2) {
-            const double2 v = *reinterpret_cast<const double2*>(&col[K & 1][16 * q + j]);
-            c[j] = v.x;
-            c[j + 1] = v.y;
-        }
-        const double raw = potf2_quad_bcast<QK>(a[KL]);             // this row's entry of column k
-        const double t = (r > K) ? raw * p : 0.0;                   // a_r[k] / pivot; rows <= k are finished
-#pragma unroll
-        for (int j = 0; j < 16; ++j) a[j] = fma(-t, c[j], a[j]);
-        // the owning part stores the factor entry: sqrt(pivot) on the diagonal, a_r[k]/sqrt(pivot) below, 0 above
-        if (q == QK) a[KL] = (r == K) ? dd * y : ((r > K) ? raw * y : 0.0);
-        if constexpr (K + 1 < IB) potf2_steps<K + 1>::run(a, col, dtol, r, q, bad);
-    }
-};
+#include "panel_device.h"
 
 // 256 threads: FOUR lanes (one DPP quad) share row r of the block, lane part q owning columns [16q, 16q+16) in 16
 // registers (every register index is a compile-time constant after unrolling).  Column k: the owning parts drop
@@ -91,7 +23,7 @@ struct potf2_steps {
 // staging tile and did wait).
 __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int64_t lda, int64_t pivot_base,
                                                     const double* __restrict__ diag0, int* __restrict__ info, double ptol) {
-    __shared__ __attribute__((aligned(16))) double col[2][IB];
+    __shared__ __attribute__((aligned(16))) double col[2][4][IB];
     __shared__ double dtol[IB];
     MGPI_CHAIN_PRIO();
     const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
@@ -105,7 +37,7 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int6
     }
     if (q == 0) dtol[r] = ptol * fabs(diag0[r]);
     int bad = 0;
-    potf2_steps<0>::run(a, col, dtol, r, q, bad);
+    potf2_rounds<0>::run(a, col, dtol, r, q, bad);
 #pragma unroll
     for (int j = 0; j < 16; j += 2) {
         const double2 v = make_double2((16 * q + j <= r) ? a[j] : 0.0, (16 * q + j + 1 <= r) ? a[j + 1] : 0.0);
@@ -126,71 +58,6 @@ int mgpi_launch_potf2(mgpi_ctx* ctx, double* A, int64_t lda, int64_t pivot_base,
     hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, pivot_base, diag0, ctx->d_info, ctx->pivot_tol);
     MGPI_HIP_TRY(hipGetLastError());
     return 0;
-}
-
-// ---- 64-wide triangular block solves ---------------------------------------------------------------------
-// Right-looking (column-sweep) substitution: once x_k is final every later unknown subtracts its coefficient
-// times x_k, so the updates of a step are independent FMAs; the division is a multiply by a reciprocal kept on
-// the diagonal of the LDS coefficient image (LAPACK's dtrsm does the same).
-//
-// Parallel shape: FOUR lanes (one DPP quad) share one row/column of unknowns, lane part q owning unknowns
-// [16q, 16q+16).  The pivot x_k is broadcast inside the quad with one quad_perm DPP move per 32 bits.
-// Variants measured with rocprofv3 at N=32768 (us per launch, multi-rhs solve / panel trsm):
-//   v1 one thread per row, coefficients from LDS in batches of 32 ............ 37 / 22  (one wave per SIMD, 69 % of
-//      the wave time in s_waitcnt on LDS latency, SQ_WAIT_ANY)
-//   v2 (this) four lanes per row, 16 waves per CU ............................. 19 / 20  (LDS-instruction bound: every
-//      quad re-reads the coefficient triangle)
-//   v3 one thread per row, coefficients by SCALAR loads from the factor in L2 . 39 / 44  (s_load latency exposed 178x)
-// fp64 facts behind this (tools/clock_probe.hip): a dependent v_fma_f64 has 32 cycles of latency (4 to issue); a
-// division is a ~15-instruction dependent chain, hence the reciprocals.
-//
-// LDS image C[k][m]: coefficient of x_k in equation m; zero where equation m does not involve x_k (so the FMAs
-// need no predicate), 1/c_kk at m == k.
-
-template <int SRC>
-__device__ __forceinline__ double quad_bcast(double v) {
-    constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);   // quad_perm: every lane reads quad lane SRC
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-
-template <int K>
-__device__ __forceinline__ void quad_step(double (&x)[16], const double (*C)[IB], int q) {
-    constexpr int QK = K / 16, KL = K % 16;
-    double c[16];
-#pragma unroll
-    for (int j = 0; j < 16; j += 2) {
-        const double2 v = *reinterpret_cast<const double2*>(&C[K][16 * q + j]);
-        c[j] = v.x;
-        c[j + 1] = v.y;
-    }
-    const double xk = quad_bcast<QK>(x[KL] * C[K][K]);       // only the owning part's product is meaningful
-#pragma unroll
-    for (int j = 0; j < 16; ++j) x[j] = fma(-c[j], xk, x[j]);
-    x[KL] = (q == QK) ? xk : x[KL];                             // the owner keeps the solved value
-}
-
-template <int K, bool FWD>
-struct quad_sweep {
-    static __device__ __forceinline__ void run(double (&x)[16], const double (*C)[IB], int q) {
-        quad_step<FWD ? IB - 1 - K : K>(x, C, q);               // FWD: steps 0, 1, .., 63; else 63, 62, .., 0
-        if constexpr (K > 0) quad_sweep<K - 1, FWD>::run(x, C, q);
-    }
-};
-
-// stage the 64x64 diagonal block as the coefficient image.  TRANSPOSE: C[k][m] = L[m][k] (else C[k][m] = L[k][m]);
-// KEEP_M_GT_K selects the triangle that is kept (m > k for the forward sweep, m < k for the backward one)
-template <bool TRANSPOSE, bool KEEP_M_GT_K>
-__device__ __forceinline__ void stage_coeff(const double* __restrict__ Ljj, int64_t ldl, double (*C)[IB], int tid) {
-#pragma unroll
-    for (int u = 0; u < IB * IB / 256; ++u) {
-        const int idx = tid + 256 * u, r = idx >> 6, cidx = idx & 63;   // L[r][cidx], coalesced
-        const double v = Ljj[r * ldl + cidx];
-        const int k = TRANSPOSE ? cidx : r, m = TRANSPOSE ? r : cidx;
-        const bool keep = KEEP_M_GT_K ? (m > k) : (m < k);
-        C[k][m] = (m == k) ? 1.0 / v : (keep ? v : 0.0);
-    }
 }
 
 // panel trsm: X L_jj^T = A, 64 columns; one 256-thread workgroup = 64 rows, 4 lanes per row.
@@ -231,7 +98,7 @@ int mgpi_launch_trsm_rows(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double*
 __global__ __launch_bounds__(256) void potf2_trsm_kernel(double* __restrict__ A, int64_t lda, int64_t pivot_base,
                                                          const double* __restrict__ diag0, int* __restrict__ info,
                                                          double* __restrict__ S, double ptol) {
-    __shared__ __attribute__((aligned(16))) double col[2][IB];
+    __shared__ __attribute__((aligned(16))) double col[2][4][IB];
     __shared__ double dtol[IB];
     __shared__ __attribute__((aligned(16))) double C[IB][IB];
     MGPI_CHAIN_PRIO();
@@ -256,7 +123,7 @@ __global__ __launch_bounds__(256) void potf2_trsm_kernel(double* __restrict__ A,
         }
     }
     int bad = 0;
-    potf2_steps<0>::run(a, col, dtol, r, q, bad);
+    potf2_rounds<0>::run(a, col, dtol, r, q, bad);
     if (blockIdx.x == 0) {
         // NOT in place: the other workgroups of this launch may not have read the unfactored block yet (with 512 of them
         // and a busy chip some start long after this one is done).  The factor goes to the scratch strip S (64 wide) and
@@ -290,6 +157,83 @@ __global__ __launch_bounds__(256) void potf2_trsm_kernel(double* __restrict__ A,
     quad_sweep<IB - 1, true>::run(x, C, q);
 #pragma unroll
     for (int j = 0; j < 16; j += 2) *reinterpret_cast<double2*>(xrow + j) = make_double2(x[j], x[j + 1]);
+}
+
+// ---- ONE launch per 64-column step of a panel (round 2) -----------------------------------------------------------------
+// Step j of a panel (diagonal block at row / column c0) used to be three launches on the chain the trailing update waits
+// for: potf2 (or potf2+trsm fused), the row trsm, and the right-looking gemm that applies the 64 new columns to the rest
+// of the panel.  Here the gemm is DEFERRED by one step and split by who needs it, and everything runs in one grid:
+//   * workgroup b < nfused ("column role"): row block b at/below the diagonal block.  Applies the previous step's columns
+//     X' (rows >= c0, columns [c0 - 64, c0)) to ITS rows of column block [c0, c0 + 64) and - redundantly, every workgroup -
+//     to the diagonal block, factors that 64 x 64 block, solves its rows against it, stores them.  The products land in
+//     MFMA accumulators, which is also the layout the factorisation and the substitution run in (panel_device.h).
+//     Workgroup 0 owns the diagonal block's rows: it stores the factor (to the scratch strip S, like potf2_trsm_kernel:
+//     late workgroups of this launch still read the unfactored block) and reports a failed pivot.
+//   * workgroups >= nfused ("update role"): one 64 x 64 tile each of the REST of the panel (column blocks right of this
+//     step's), to which they apply X' - the part of the deferred gemm that is not on this step's critical path.
+// The chain per step is then one launch of (two contraction-64 products + 64 x 64 Cholesky + 64-row substitution).
+__global__ __launch_bounds__(256) void panel_step_kernel(double* __restrict__ A, int64_t lda, int64_t c0, int has_prev, int nfused,
+                                                         int rest_cols, int64_t pivot_base, const double* __restrict__ diag0,
+                                                         int* __restrict__ info, double* __restrict__ S, double ptol) {
+    __shared__ panel_lds s;
+    MGPI_CHAIN_PRIO();
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int64_t cp = c0 - IB, c1 = c0 + IB;
+    panel_double4_t acc[4];
+    if ((int)blockIdx.x >= nfused) {
+        // update role: tile (ti, tj) of the rows >= c1, column blocks c1 + 64 tj (tj < rest_cols); only tiles on/below the diagonal
+        int t = (int)blockIdx.x - nfused, tj = 0;
+        const int nrows1 = nfused - 1;
+        while (t >= nrows1 - tj) { t -= nrows1 - tj; ++tj; }
+        const int ti = tj + t;
+        double* C = A + (c1 + (int64_t)IB * ti) * lda + c1 + (int64_t)IB * tj;
+        panel_load(acc, C, lda, w, g, c, false);
+        panel_gemm_nt(acc, A + (c1 + (int64_t)IB * ti + 16 * w + c) * lda + cp + 2 * g, A + (c1 + (int64_t)IB * tj + c) * lda + cp + 2 * g, lda, 0, 4);
+        panel_store(acc, C, lda, w, g, c);
+        return;
+    }
+    const int b = blockIdx.x;
+    const int64_t r0 = c0 + (int64_t)IB * b;                      // this workgroup's rows
+    if (tid < IB) s.dtol[tid] = ptol * fabs(diag0[tid]);
+    // the diagonal block, current as of the previous step
+    panel_double4_t accD[4];
+    panel_load(accD, A + c0 * lda + c0, lda, w, g, c, true);
+    if (has_prev) panel_gemm_nt(accD, A + (c0 + 16 * w + c) * lda + cp + 2 * g, A + (c0 + c) * lda + cp + 2 * g, lda, 0, w + 1);
+    if (b > 0) {
+        panel_load(acc, A + r0 * lda + c0, lda, w, g, c, false);
+        if (has_prev) panel_gemm_nt(acc, A + (r0 + 16 * w + c) * lda + cp + 2 * g, A + (c0 + c) * lda + cp + 2 * g, lda, 0, 4);
+    }
+    int bad = 0;
+    potf2_acc_rounds<0>::run(accD, s, w, g, c, bad, b == 0 ? S : nullptr);
+    if (b == 0) {
+        if (tid == 0 && bad != 0) {
+            const int cand = (int)(pivot_base + bad);
+            int old = atomicCAS(info, 0, cand);
+            while (old != 0 && old > cand) {
+                const int prev = atomicCAS(info, old, cand);
+                if (prev == old) break;
+                old = prev;
+            }
+        }
+        return;
+    }
+    __syncthreads();                                               // the factor's LDS images are complete
+    trsm_acc_rounds<0>::run(acc, s, w, g, c, A + (r0 + 16 * w + c) * lda + c0);
+}
+
+// one step: diagonal block at (c0, c0) of the matrix A (c0 absolute), `rows_below` rows below the block, the panel ends at
+// column panel_end; has_prev: the columns [c0 - 64, c0) of this panel were solved by the previous step and still have to be
+// applied to everything right of them
+static int launch_panel_step(mgpi_ctx* ctx, double* A, int64_t lda, int64_t c0, int has_prev, int64_t rows_below, int64_t panel_end,
+                             int64_t pivot_base, const double* diag0, double* S) {
+    const int nfused = (int)(1 + rows_below / IB);
+    const int rest_cols = has_prev ? (int)((panel_end - c0 - IB) / IB) : 0;
+    int64_t nrest = 0;
+    for (int tj = 0; tj < rest_cols; ++tj) nrest += nfused - 1 - tj;       // tiles on/below the diagonal, rows >= c0 + 64
+    hipLaunchKernelGGL(panel_step_kernel, dim3((unsigned)(nfused + nrest)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused,
+                       rest_cols, pivot_base, diag0, ctx->d_info, S, ctx->pivot_tol);
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 // A[64 k + i][64 k + j] = S[64 k + i][j]: the factored diagonal blocks back into the matrix
@@ -516,7 +460,20 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     // run beside it (C3 with fusion everywhere: potrf 188 -> 192 ms).  MGPI_PANEL_FUSE=0 keeps them apart.
     static const bool panel_fused = getenv("MGPI_PANEL_FUSE") ? atoi(getenv("MGPI_PANEL_FUSE")) != 0 : true;
     static const int64_t fuse_rows = getenv("MGPI_PANEL_FUSE_ROWS") ? atoll(getenv("MGPI_PANEL_FUSE_ROWS")) : 8192;
+    // ONE launch per 64-column step (panel_step_kernel) for the panels whose first diagonal block has at most
+    // MGPI_PANEL_STEP_ROWS rows below it; MGPI_PANEL_STEP=0 keeps the round-1 kernels everywhere (developer switch, tested).
+    static const bool panel_step = getenv("MGPI_PANEL_STEP") ? atoi(getenv("MGPI_PANEL_STEP")) != 0 : true;
+    static const int64_t step_rows = getenv("MGPI_PANEL_STEP_ROWS") ? atoll(getenv("MGPI_PANEL_STEP_ROWS")) : fuse_rows;
+    int64_t strip_first = pn / IB;                      // first 64-block whose factored diagonal block waits in the scratch strip
     auto factor_panel = [&](int64_t r0, int64_t w) -> int {
+        if (panel_step && pn - r0 - IB <= step_rows) {
+            for (int64_t c0 = r0; c0 < r0 + w; c0 += IB) {
+                MGPI_TRY(launch_panel_step(ctx, A, lda, c0, c0 > r0, pn - c0 - IB, r0 + w, pivot_base + c0, ctx->d_diag + c0,
+                                           ctx->d_diag + ctx->diag_len + c0 * IB));
+                if (c0 / IB < strip_first) strip_first = c0 / IB;
+            }
+            return 0;
+        }
         for (int64_t c0 = r0; c0 < r0 + w; c0 += IB) {
             const int64_t kk = c0 - r0;
             if (kk > 0 && !panel_right)   // A[c0:pn, c0:c0+64] -= A[c0:pn, r0:c0] * A[c0:c0+64, r0:c0]^T
@@ -525,6 +482,7 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
             if (panel_fused && pn - c0 - IB <= fuse_rows) {
                 MGPI_TRY(mgpi_launch_potf2_trsm(ctx, A + c0 * lda + c0, lda, pivot_base + c0, ctx->d_diag + c0, pn - c0 - IB,
                                                 ctx->d_diag + ctx->diag_len + c0 * IB));
+                if (c0 / IB < strip_first) strip_first = c0 / IB;
             } else {
                 MGPI_TRY(mgpi_launch_potf2(ctx, A + c0 * lda + c0, lda, pivot_base + c0, ctx->d_diag + c0));
                 MGPI_TRY(mgpi_launch_trsm_rows(ctx, A + c0 * lda + c0, lda, A + (c0 + IB) * lda + c0, lda, pn - c0 - IB));
@@ -638,13 +596,9 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     }
     if (lookahead && panel_on_side) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
 
-    if (panel_fused) {   // the diagonal blocks factored by potf2_trsm_kernel wait in the scratch strip
-        int64_t first = (pn - IB - fuse_rows + IB - 1) / IB;          // smallest k with pn - 64 k - 64 <= fuse_rows
-        if (first < 0) first = 0;
-        if (first < pn / IB)
-            hipLaunchKernelGGL(diag_blocks_back_kernel, dim3((unsigned)(pn / IB - first)), dim3(256), 0, ctx->stream, A, lda,
-                               ctx->d_diag + ctx->diag_len, first);
-    }
+    if (strip_first < pn / IB)     // the diagonal blocks factored by panel_step_kernel / potf2_trsm_kernel wait in the scratch strip
+        hipLaunchKernelGGL(diag_blocks_back_kernel, dim3((unsigned)(pn / IB - strip_first)), dim3(256), 0, ctx->stream, A, lda,
+                           ctx->d_diag + ctx->diag_len, strip_first);
     mgpi_prof_end(ctx, 2);
 
     hipLaunchKernelGGL(logdiag_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, n, ctx->d_scal + (keep_status ? 1 : 0),
