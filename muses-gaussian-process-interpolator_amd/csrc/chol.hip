@@ -172,17 +172,26 @@ __global__ __launch_bounds__(256) void potf2_trsm_kernel(double* __restrict__ A,
 //   * workgroups >= nfused ("update role"): one 64 x 64 tile each of the REST of the panel (column blocks right of this
 //     step's), to which they apply X' - the part of the deferred gemm that is not on this step's critical path.
 // The chain per step is then one launch of (two contraction-64 products + 64 x 64 Cholesky + 64-row substitution).
+// `mode` splits the work for LARGE panels, where hundreds of workgroups repeating the 64 x 64 factorisation would take CU
+// time from the trailing update that runs beside the panel:
+//   mode 0  everything in one launch (every column-role workgroup factors the diagonal block itself)
+//   mode 1  one workgroup: update + factor the diagonal block, store it (strip S) and its LDS images (Lt, 1/diag) to F
+//   mode 2  the rest: column-role workgroups for the row blocks BELOW the diagonal block read the images from F
+//           instead of factoring, plus the update-role workgroups
+#define PANEL_F_DOUBLES (IB * IB + IB)
 __global__ __launch_bounds__(256) void panel_step_kernel(double* __restrict__ A, int64_t lda, int64_t c0, int has_prev, int nfused,
                                                          int rest_cols, int64_t pivot_base, const double* __restrict__ diag0,
-                                                         int* __restrict__ info, double* __restrict__ S, double ptol) {
+                                                         int* __restrict__ info, double* __restrict__ S, double ptol, int mode,
+                                                         double* __restrict__ F) {
     __shared__ panel_lds s;
     MGPI_CHAIN_PRIO();
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     const int64_t cp = c0 - IB, c1 = c0 + IB;
     panel_double4_t acc[4];
-    if ((int)blockIdx.x >= nfused) {
+    const int first_fused = (mode == 2) ? 1 : 0;                 // mode 2 has no workgroup for the diagonal block's rows
+    if ((int)blockIdx.x + first_fused >= nfused) {
         // update role: tile (ti, tj) of the rows >= c1, column blocks c1 + 64 tj (tj < rest_cols); only tiles on/below the diagonal
-        int t = (int)blockIdx.x - nfused, tj = 0;
+        int t = (int)blockIdx.x + first_fused - nfused, tj = 0;
         const int nrows1 = nfused - 1;
         while (t >= nrows1 - tj) { t -= nrows1 - tj; ++tj; }
         const int ti = tj + t;
@@ -192,30 +201,40 @@ __global__ __launch_bounds__(256) void panel_step_kernel(double* __restrict__ A,
         panel_store(acc, C, lda, w, g, c);
         return;
     }
-    const int b = blockIdx.x;
+    const int b = (int)blockIdx.x + first_fused;
     const int64_t r0 = c0 + (int64_t)IB * b;                      // this workgroup's rows
-    if (tid < IB) s.dtol[tid] = ptol * fabs(diag0[tid]);
-    // the diagonal block, current as of the previous step
-    panel_double4_t accD[4];
-    panel_load(accD, A + c0 * lda + c0, lda, w, g, c, true);
-    if (has_prev) panel_gemm_nt(accD, A + (c0 + 16 * w + c) * lda + cp + 2 * g, A + (c0 + c) * lda + cp + 2 * g, lda, 0, w + 1);
     if (b > 0) {
         panel_load(acc, A + r0 * lda + c0, lda, w, g, c, false);
         if (has_prev) panel_gemm_nt(acc, A + (r0 + 16 * w + c) * lda + cp + 2 * g, A + (c0 + c) * lda + cp + 2 * g, lda, 0, 4);
     }
-    int bad = 0;
-    potf2_acc_rounds<0>::run(accD, s, w, g, c, bad, b == 0 ? S : nullptr);
-    if (b == 0) {
-        if (tid == 0 && bad != 0) {
-            const int cand = (int)(pivot_base + bad);
-            int old = atomicCAS(info, 0, cand);
-            while (old != 0 && old > cand) {
-                const int prev = atomicCAS(info, old, cand);
-                if (prev == old) break;
-                old = prev;
+    if (mode == 2) {
+        for (int i = tid; i < IB * IB; i += 256) (&s.Lt[0][0])[i] = F[i];
+        if (tid < IB) s.invd[tid] = F[IB * IB + tid];
+    } else {
+        if (tid < IB) s.dtol[tid] = ptol * fabs(diag0[tid]);
+        // the diagonal block, current as of the previous step
+        panel_double4_t accD[4];
+        panel_load(accD, A + c0 * lda + c0, lda, w, g, c, true);
+        if (has_prev) panel_gemm_nt(accD, A + (c0 + 16 * w + c) * lda + cp + 2 * g, A + (c0 + c) * lda + cp + 2 * g, lda, 0, w + 1);
+        int bad = 0;
+        potf2_acc_rounds<0>::run(accD, s, w, g, c, bad, b == 0 ? S : nullptr);
+        if (b == 0) {
+            if (tid == 0 && bad != 0) {
+                const int cand = (int)(pivot_base + bad);
+                int old = atomicCAS(info, 0, cand);
+                while (old != 0 && old > cand) {
+                    const int prev = atomicCAS(info, old, cand);
+                    if (prev == old) break;
+                    old = prev;
+                }
             }
+            if (mode == 1) {
+                __syncthreads();
+                for (int i = tid; i < IB * IB; i += 256) F[i] = (&s.Lt[0][0])[i];
+                if (tid < IB) F[IB * IB + tid] = s.invd[tid];
+            }
+            return;
         }
-        return;
     }
     __syncthreads();                                               // the factor's LDS images are complete
     trsm_acc_rounds<0>::run(acc, s, w, g, c, A + (r0 + 16 * w + c) * lda + c0);
@@ -223,15 +242,24 @@ __global__ __launch_bounds__(256) void panel_step_kernel(double* __restrict__ A,
 
 // one step: diagonal block at (c0, c0) of the matrix A (c0 absolute), `rows_below` rows below the block, the panel ends at
 // column panel_end; has_prev: the columns [c0 - 64, c0) of this panel were solved by the previous step and still have to be
-// applied to everything right of them
+// applied to everything right of them.  split: two launches (diagonal block, then the rows) instead of one
 static int launch_panel_step(mgpi_ctx* ctx, double* A, int64_t lda, int64_t c0, int has_prev, int64_t rows_below, int64_t panel_end,
-                             int64_t pivot_base, const double* diag0, double* S) {
+                             int64_t pivot_base, const double* diag0, double* S, bool split) {
     const int nfused = (int)(1 + rows_below / IB);
     const int rest_cols = has_prev ? (int)((panel_end - c0 - IB) / IB) : 0;
     int64_t nrest = 0;
     for (int tj = 0; tj < rest_cols; ++tj) nrest += nfused - 1 - tj;       // tiles on/below the diagonal, rows >= c0 + 64
-    hipLaunchKernelGGL(panel_step_kernel, dim3((unsigned)(nfused + nrest)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused,
-                       rest_cols, pivot_base, diag0, ctx->d_info, S, ctx->pivot_tol);
+    double* F = ctx->d_scal + 64;                                          // 64 x 64 + 64 doubles of the ctx's scalar scratch
+    if (!split) {
+        hipLaunchKernelGGL(panel_step_kernel, dim3((unsigned)(nfused + nrest)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused,
+                           rest_cols, pivot_base, diag0, ctx->d_info, S, ctx->pivot_tol, 0, F);
+    } else {
+        hipLaunchKernelGGL(panel_step_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused, rest_cols, pivot_base,
+                           diag0, ctx->d_info, S, ctx->pivot_tol, 1, F);
+        if (nfused - 1 + nrest > 0)
+            hipLaunchKernelGGL(panel_step_kernel, dim3((unsigned)(nfused - 1 + nrest)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev,
+                               nfused, rest_cols, pivot_base, diag0, ctx->d_info, S, ctx->pivot_tol, 2, F);
+    }
     MGPI_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -464,12 +492,16 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     // MGPI_PANEL_STEP_ROWS rows below it; MGPI_PANEL_STEP=0 keeps the round-1 kernels everywhere (developer switch, tested).
     static const bool panel_step = getenv("MGPI_PANEL_STEP") ? atoi(getenv("MGPI_PANEL_STEP")) != 0 : true;
     static const int64_t step_rows = getenv("MGPI_PANEL_STEP_ROWS") ? atoll(getenv("MGPI_PANEL_STEP_ROWS")) : fuse_rows;
+    // larger panels: the same kernel as two launches per step (diagonal block, then the rows); MGPI_PANEL_STEP_SPLIT=0 leaves
+    // them to the round-1 kernels
+    static const bool step_split = getenv("MGPI_PANEL_STEP_SPLIT") ? atoi(getenv("MGPI_PANEL_STEP_SPLIT")) != 0 : true;
     int64_t strip_first = pn / IB;                      // first 64-block whose factored diagonal block waits in the scratch strip
     auto factor_panel = [&](int64_t r0, int64_t w) -> int {
-        if (panel_step && pn - r0 - IB <= step_rows) {
+        if (panel_step && (pn - r0 - IB <= step_rows || step_split)) {
+            const bool split = pn - r0 - IB > step_rows;
             for (int64_t c0 = r0; c0 < r0 + w; c0 += IB) {
                 MGPI_TRY(launch_panel_step(ctx, A, lda, c0, c0 > r0, pn - c0 - IB, r0 + w, pivot_base + c0, ctx->d_diag + c0,
-                                           ctx->d_diag + ctx->diag_len + c0 * IB));
+                                           ctx->d_diag + ctx->diag_len + c0 * IB, split));
                 if (c0 / IB < strip_first) strip_first = c0 / IB;
             }
             return 0;

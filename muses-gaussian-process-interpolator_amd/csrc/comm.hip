@@ -240,7 +240,7 @@ extern "C" int mgpi_comm_barrier(mgpi_comm* comm, mgpi_ctx* ctx) {
                  comm->device);
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
     if (comm->size > 1) {
-        double* token = ctx->d_scal + 4000;          // scratch scalar nothing else uses
+        double* token = ctx->d_scal + 8000;          // scratch scalar nothing else uses
         MGPI_HIP_TRY(hipMemsetAsync(token, 0, sizeof(double), ctx->stream));
         MGPI_RCCL_TRY(g_rccl.AllReduce(token, token, 1, ncclDouble, ncclSum, comm->comm, ctx->stream));
     }

@@ -64,7 +64,7 @@ extern "C" int mgpi_ctx_create(int device_id, int nb, mgpi_ctx** out) {
     MGPI_HIP_TRY(hipEventCreate(&c->ev0));
     MGPI_HIP_TRY(hipEventCreate(&c->ev1));
     MGPI_HIP_TRY(hipMalloc((void**)&c->d_info, 64));
-    MGPI_HIP_TRY(hipMalloc((void**)&c->d_scal, 4096 * sizeof(double)));
+    MGPI_HIP_TRY(hipMalloc((void**)&c->d_scal, 8192 * sizeof(double)));
     MGPI_HIP_TRY(hipMemset(c->d_info, 0, 64));
     c->pool = new mgpi_pool();
     {
@@ -619,6 +619,7 @@ int mgpi_make_terms(const mgpi_kernel_desc* terms, int nterms, int d, mgpi_terms
     memset(out, 0, sizeof(*out));
     out->nterms = nterms;
     out->d = d;
+    int exact = 1;
     for (int t = 0; t < nterms; ++t) {
         MGPI_REQUIRE(terms[t].type == MGPI_TERM_SE || terms[t].type == MGPI_TERM_WHITE || terms[t].type == MGPI_TERM_MATERN,
                      "kernel terms: term %d has unsupported type %d", t, terms[t].type);
@@ -626,8 +627,10 @@ int mgpi_make_terms(const mgpi_kernel_desc* terms, int nterms, int d, mgpi_terms
         out->sig2[t] = terms[t].sigma * terms[t].sigma;          // sigma**2
         if (terms[t].type == MGPI_TERM_SE || terms[t].type == MGPI_TERM_MATERN)
             for (int k = 0; k < d; ++k) {
-                // 1/length**2 ; a zero length gives inf, like the reference's division
-                out->inv_l2[t][k] = 1.0 / (terms[t].length[k] * terms[t].length[k]);
+                const double l2 = terms[t].length[k] * terms[t].length[k];     // lengths**2 (kernels.py:185)
+                out->l2[t][k] = l2;
+                out->inv_l2[t][k] = 1.0 / l2;
+                if (!(l2 >= 2.3e-308 && l2 <= 1e300 && out->inv_l2[t][k] >= 2.3e-308)) exact = 0;   // zero / inf / NaN / subnormal: divide for real
             }
         if (terms[t].type == MGPI_TERM_MATERN) {
             const double o = terms[t].order;
@@ -663,5 +666,10 @@ int mgpi_make_terms(const mgpi_kernel_desc* terms, int nterms, int d, mgpi_terms
             }
         }
     }
+    out->exact_div = exact;
+    out->fast_mix = 0;
+    if (exact && nterms == 1 && terms[0].type == MGPI_TERM_SE) out->fast_mix = 1;
+    if (exact && nterms == 2 && terms[0].type == MGPI_TERM_SE && terms[1].type == MGPI_TERM_WHITE) out->fast_mix = 2;
+    if (getenv("MGPI_COV_FAST") && atoi(getenv("MGPI_COV_FAST")) == 0) out->fast_mix = 0;      // developer switch: the general loop
     return 0;
 }

@@ -8,7 +8,7 @@
 // out[i][j] = k(x1_i, x2_j) for i < n1, j < n2; padded entries (i >= n1 or j >= n2, up to p1 x p2) are written
 // as 0, or as the identity when pad_identity (so that the padded K stays positive definite, its Cholesky
 // factor is [[L,0],[0,I]] and logdet is unchanged).
-template <int D>
+template <int D, int MIX>
 __global__ __launch_bounds__(256) void cov_tile_kernel(mgpi_terms_dev t, const double* __restrict__ x1, int64_t ldx1,
                                                        int64_t n1, const double* __restrict__ x2, int64_t ldx2,
                                                        int64_t n2, int lower_only, int pad_identity,
@@ -50,8 +50,8 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(mgpi_terms_dev t, const d
         for (int c = 0; c < 2; ++c) {
             const int64_t j = col0 + 2 * tx + 32 * c;
             double2 v;
-            v.x = mgpi_cov_entry<D>(t, a[r], b[2 * c]);
-            v.y = mgpi_cov_entry<D>(t, a[r], b[2 * c + 1]);
+            v.x = mgpi_cov_entry<D, MIX>(t, a[r], b[2 * c]);
+            v.y = mgpi_cov_entry<D, MIX>(t, a[r], b[2 * c + 1]);
             if (i >= n1 || j >= n2) v.x = (pad_identity && i == j) ? 1.0 : 0.0;
             if (i >= n1 || j + 1 >= n2) v.y = (pad_identity && i == j + 1) ? 1.0 : 0.0;
             *reinterpret_cast<double2*>(&out[i * ldo + j]) = v;
@@ -85,22 +85,25 @@ int mgpi_launch_cov(mgpi_ctx* ctx, const mgpi_terms_dev& t, const double* x1, in
                  (long long)p1, (long long)p2, COV_T);
     MGPI_REQUIRE(p1 / COV_T <= 65535, "cov: too many row tiles");
     dim3 grid((unsigned)(p2 / COV_T), (unsigned)(p1 / COV_T)), block(256);
-#define MGPI_COV_CASE(DV)                                                                                     \
-    case DV:                                                                                                  \
-        hipLaunchKernelGGL(cov_tile_kernel<DV>, grid, block, 0, ctx->stream, t, x1, ldx1, n1, x2, ldx2, n2,  \
-                           lower_only, pad_identity, out, ldo);                                               \
+#define MGPI_COV_LAUNCH(DV, MV)                                                                                   \
+    hipLaunchKernelGGL((cov_tile_kernel<DV, MV>), grid, block, 0, ctx->stream, t, x1, ldx1, n1, x2, ldx2, n2,     \
+                       lower_only, pad_identity, out, ldo)
+#define MGPI_COV_CASE(DV)                                                                                         \
+    case DV:                                                                                                      \
+        if (t.fast_mix == 1) MGPI_COV_LAUNCH(DV, 1);                                                              \
+        else if (t.fast_mix == 2) MGPI_COV_LAUNCH(DV, 2);                                                         \
+        else MGPI_COV_LAUNCH(DV, 0);                                                                              \
         break;
     switch (t.d) {
         MGPI_COV_CASE(1)
         MGPI_COV_CASE(2)
         MGPI_COV_CASE(3)
         MGPI_COV_CASE(4)
-        MGPI_COV_CASE(5)
-        MGPI_COV_CASE(6)
-        default:
-            hipLaunchKernelGGL(cov_tile_kernel<0>, grid, block, 0, ctx->stream, t, x1, ldx1, n1, x2, ldx2, n2,
-                               lower_only, pad_identity, out, ldo);
+        case 5: MGPI_COV_LAUNCH(5, 0); break;
+        case 6: MGPI_COV_LAUNCH(6, 0); break;
+        default: MGPI_COV_LAUNCH(0, 0);
     }
+#undef MGPI_COV_LAUNCH
 #undef MGPI_COV_CASE
     MGPI_HIP_TRY(hipGetLastError());
     return 0;

@@ -83,6 +83,60 @@ __device__ __forceinline__ double mgpi_matern_shape(double x, int nl, double mu,
     return norm * t0;
 }
 
+// a / b correctly rounded from rb = RN(1/b): q = RN(a rb), the residual a - q b is exact in an fma, one correction step
+// (Markstein).  Holds for normal finite b (mgpi_terms_dev::exact_div); the reference divides (kernels.py:185), and
+// an error of one ulp in r = sum (dx/l)^2 becomes r ulps in exp(-r) - the reason round 1 could only promise 5e-13 on K.
+__device__ __forceinline__ double mgpi_div_rn(double a, double b, double rb) {
+    const double q = __dmul_rn(a, rb);
+    return fma(fma(-q, b, a), rb, q);
+}
+
+// exp(-r) for r >= 0 (also NaN -> NaN, +inf -> 0), inlined: k = rint(-r / ln 2), t = -r - k ln 2 in two fma steps
+// (ln2_hi carries 32 trailing zero bits: k ln2_hi is exact for |k| < 2^11), a degree-13 Taylor polynomial on
+// |t| <= ln2 / 2 (remainder t^14 / 14! < 5e-18), scaling by 2^k in one v_ldexp_f64 (gradual underflow like libm).
+// 21 instructions against ~45 for the library call, whose argument checks and two-sided range handling this
+// one-sided form does not need.  Measured against numpy's exp over r in [0, 745]: max 1 ulp (tests/test_gpu_parity.py).
+__device__ __forceinline__ double mgpi_exp_neg(double r) {
+    const double x = -r;
+    const double kf = __builtin_rint(x * 1.4426950408889634);
+    double t = fma(-kf, 6.93147180369123816490e-01, x);
+    t = fma(-kf, 1.90821492927058770002e-10, t);
+    double p = 1.6059043836821613e-10;                         // 1/13!
+    p = fma(p, t, 2.08767569878681e-09);                       // 1/12!
+    p = fma(p, t, 2.505210838544172e-08);                      // 1/11!
+    p = fma(p, t, 2.755731922398589e-07);                      // 1/10!
+    p = fma(p, t, 2.7557319223985893e-06);                     // 1/9!
+    p = fma(p, t, 2.48015873015873e-05);                       // 1/8!
+    p = fma(p, t, 1.984126984126984e-04);                      // 1/7!
+    p = fma(p, t, 1.388888888888889e-03);                      // 1/6!
+    p = fma(p, t, 8.333333333333333e-03);                      // 1/5!
+    p = fma(p, t, 4.1666666666666664e-02);                     // 1/4!
+    p = fma(p, t, 1.6666666666666666e-01);                     // 1/3!
+    p = fma(p, t, 0.5);
+    p = fma(p, t, 1.0);
+    p = fma(p, t, 1.0);
+    const double v = ldexp(p, (int)kf);
+    return (r > 746.0) ? 0.0 : v;                              // below the smallest subnormal (and r = +inf, where t is NaN)
+}
+
+// the two commonest kernels without the term loop: MIX 1 = one SquaredExponential, MIX 2 = SquaredExponential +
+// WhiteNoise (kernel + nugget, kernels.py:54-59).  Same operations in the same order as the general loop below.
+template <int D, int MIX>
+__device__ __forceinline__ double mgpi_cov_entry_fast(const mgpi_terms_dev& t, const double* __restrict__ a,
+                                                      const double* __restrict__ b) {
+    double r = 0.0;
+    bool same = true;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const double df = a[k] - b[k];
+        same = same && (a[k] == b[k]);
+        r = __dadd_rn(r, mgpi_div_rn(__dmul_rn(df, df), t.l2[0][k], t.inv_l2[0][k]));
+    }
+    double val = __dmul_rn(t.sig2[0], mgpi_exp_neg(r));
+    if (MIX == 2) val = __dadd_rn(val, same ? t.sig2[1] : 0.0);
+    return val;
+}
+
 // D > 0: compile-time dimensionality (registers, fully unrolled); D == 0: runtime t.d (<= MGPI_MAX_D)
 // summands [lo, hi) of the kernel: the NNGP path needs kernel-only and nugget-only sums next to the full one
 template <int D>
@@ -106,13 +160,14 @@ __device__ __forceinline__ double mgpi_cov_entry_range(const mgpi_terms_dev& t, 
             double r = 0.0;
 #pragma unroll
             for (int k = 0; k < ((D > 0) ? D : MGPI_MAX_D); ++k)
-                if (k < nd) r = __dadd_rn(r, __dmul_rn(diff2[k], t.inv_l2[s][k]));   // sum_d (x1-x2)**2/length_d**2, left to right, no fma contraction
-            val = __dadd_rn(val, __dmul_rn(t.sig2[s], exp(-r)));   // sigma**2 * exp(-r), rounded product then add
+                if (k < nd)   // sum_d (x1-x2)**2/length_d**2, left to right; the quotient correctly rounded like the reference's division
+                    r = __dadd_rn(r, t.exact_div ? mgpi_div_rn(diff2[k], t.l2[s][k], t.inv_l2[s][k]) : diff2[k] / t.l2[s][k]);
+            val = __dadd_rn(val, __dmul_rn(t.sig2[s], mgpi_exp_neg(r)));   // sigma**2 * exp(-r), rounded product then add
         } else if (t.type[s] == MGPI_TERM_MATERN) {
             double r = 0.0;
 #pragma unroll
             for (int k = 0; k < ((D > 0) ? D : MGPI_MAX_D); ++k)
-                if (k < nd) r = __dadd_rn(r, __dmul_rn(diff2[k], t.inv_l2[s][k]));
+                if (k < nd) r = __dadd_rn(r, t.exact_div ? mgpi_div_rn(diff2[k], t.l2[s][k], t.inv_l2[s][k]) : diff2[k] / t.l2[s][k]);
             const double diff = sqrt(t.mat_two_o[s]) * sqrt(r);    // (2*o)**0.5 * sum(...)**0.5   (kernels.py:161)
             double m = 1.0;                                        // r -> 0 limit of the bracket below (the reference: NaN)
             if (t.mat_half_p[s] >= 0) {
@@ -131,8 +186,10 @@ __device__ __forceinline__ double mgpi_cov_entry_range(const mgpi_terms_dev& t, 
     return val;
 }
 
-template <int D>
+// MIX is a compile-time copy of t.fast_mix (the launchers switch on it); D == 0 always takes the general loop
+template <int D, int MIX = 0>
 __device__ __forceinline__ double mgpi_cov_entry(const mgpi_terms_dev& t, const double* __restrict__ a,
                                                  const double* __restrict__ b) {
-    return mgpi_cov_entry_range<D>(t, a, b, 0, t.nterms);
+    if constexpr (D > 0 && MIX > 0) return mgpi_cov_entry_fast<D, MIX>(t, a, b);
+    else return mgpi_cov_entry_range<D>(t, a, b, 0, t.nterms);
 }

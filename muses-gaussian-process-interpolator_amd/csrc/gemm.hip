@@ -645,6 +645,14 @@ static int launch_shape(mgpi_ctx* ctx, int lower_only, int64_t m, int64_t n, int
         if (use_glds()) return launch_one<128, 128, AK, BKM, true, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
         return launch_one<128, 128, AK, BKM, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
     }
+    // Skinny updates (the next panel's block column: t x 512 with t <= 8192) give fewer 128 x 128 tiles than the chip has
+    // workgroup slots (256 CUs x 2): half the CUs idle for the length of one K = 512 tile, on the chain the next panel waits
+    // for.  Narrower tiles fill the chip (N = 8192: 240 tiles -> 480; measured 184 -> ... us per column update).
+    static const int64_t skinny = getenv("MGPI_GEMM_SKINNY_TILES") ? atoll(getenv("MGPI_GEMM_SKINNY_TILES")) : 448;
+    if (m % 128 == 0 && n % 128 == 0 && (m / 128) * (n / 128) < skinny) {
+        if ((m / 128) * (n / 64) < skinny) return launch_one<64, 64, AK, BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
+        return launch_one<128, 64, AK, BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
+    }
     if (m % 128 == 0 && n % 128 == 0) {
         if (use_pp((m / 128) * (n / 128))) return launch_pp<AK, BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
         if constexpr (!AK) if (use_pipe()) return launch_pipe<BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);

@@ -37,7 +37,7 @@ struct mgpi_ctx {
     mgpi_prof_slot* prof;         // [MGPI_PROF_SLOTS]: 0 trailing update (lower syrk), 1 panel, 2 whole potrf, 3 next-panel
                                   // column update, 4 big update of the multi-rhs forward solve (variance), 5 fused predict mean
     int* d_info;                  // device: first failing pivot (0 = none)
-    double* d_scal;               // device scratch scalars (logdet partials etc.), 4096 doubles
+    double* d_scal;               // device scratch, 8192 doubles: [0] logdet, [1] status accumulator, [64, 64 + 64*64 + 64) panel images, [8000] barrier token
     double* d_diag;               // diag(K) before factoring (pivot threshold), grown on demand
     int64_t diag_len;
     double* work;                 // device workspace, grown on demand
@@ -104,7 +104,11 @@ struct mgpi_terms_dev {
     int d;
     int type[MGPI_MAX_TERMS];
     double sig2[MGPI_MAX_TERMS];                    // sigma**2              (kernels.py:131,185)
-    double inv_l2[MGPI_MAX_TERMS][MGPI_MAX_D];      // 1/length_d**2         (kernels.py:185,161)
+    double l2[MGPI_MAX_TERMS][MGPI_MAX_D];          // length_d**2           (kernels.py:185,161)
+    double inv_l2[MGPI_MAX_TERMS][MGPI_MAX_D];      // RN(1/length_d**2): with one fma correction the quotient (x1-x2)**2/length**2
+                                                    // comes out correctly rounded, i.e. equal to the reference's division
+    int exact_div;                                  // every length**2 is a normal finite number: the corrected product is valid
+    int fast_mix;                                   // 1: one SE term; 2: SE + WhiteNoise (kernel + nugget); 0: the general loop
     // Matern terms: order o = nl + mu with |mu| <= 1/2, and the x-independent constants of Temme's series
     int mat_nl[MGPI_MAX_TERMS];
     double mat_mu[MGPI_MAX_TERMS], mat_two_o[MGPI_MAX_TERMS], mat_norm[MGPI_MAX_TERMS], mat_order[MGPI_MAX_TERMS];

@@ -290,7 +290,7 @@ __device__ __forceinline__ void panel_gemm_nt(panel_double4_t (&acc)[4], const d
 //   4. the same lane stores the finished entry L[row][K + g] = w_g / sqrt(d_g): to the transposed LDS image Lt (what the
 //      substitution that follows reads), its reciprocal diagonal, and (S != nullptr) the row-major 64-wide global strip.
 // Rows above the block (row < K + t) produce zeros everywhere.  The pivots d_t are the unblocked algorithm's pivots up to
-// rounding, so the acceptance rule d_t > tol * K_tt(original) is unchanged; a failed pivot is replaced by 1 (and reported).
+// rounding, so the acceptance rule d_t > tol * K_tt(original) is unchanged.
 template <int K>
 struct potf2_acc_rounds {
     static __device__ __forceinline__ void run(panel_double4_t (&acc)[4], panel_lds& s, int w, int g, int c, int& bad,
@@ -307,26 +307,25 @@ struct potf2_acc_rounds {
         const int row = 16 * w + c;
         const panel_double4_t ar = panel_row4(s.raw[B][row]);
         // pivot block, LDL^T
-        const bool ok0 = p00 > s.dtol[K];
-        const double d0 = ok0 ? p00 : 1.0, rd0 = rcp_refined(d0);
+        // (a failed pivot is reported, not repaired: what follows it is undefined - NaN / inf - as the header says; keeping
+        // the compare-and-select off the dependent chain is worth ~8 dependent instructions per round)
+        const double d0 = p00, rd0 = rcp_refined(d0);
+        const bool ok0 = d0 > s.dtol[K];
         const double m10 = p10 * rd0, m20 = p20 * rd0, m30 = p30 * rd0;
-        const double e1 = fma(-m10, p10, p11);
-        const bool ok1 = e1 > s.dtol[K + 1];
-        const double d1 = ok1 ? e1 : 1.0, rd1 = rcp_refined(d1);
+        const double d1 = fma(-m10, p10, p11), rd1 = rcp_refined(d1);
+        const bool ok1 = d1 > s.dtol[K + 1];
         const double q21 = fma(-m20, p10, p21), q31 = fma(-m30, p10, p31);
         const double m21 = q21 * rd1, m31 = q31 * rd1;
-        const double e2 = fma(-m21, q21, fma(-m20, p20, p22));
-        const bool ok2 = e2 > s.dtol[K + 2];
-        const double d2 = ok2 ? e2 : 1.0, rd2 = rcp_refined(d2);
+        const double d2 = fma(-m21, q21, fma(-m20, p20, p22)), rd2 = rcp_refined(d2);
+        const bool ok2 = d2 > s.dtol[K + 2];
         const double q32 = fma(-m31, q21, fma(-m30, p20, p32));
         const double m32 = q32 * rd2;
-        const double e3 = fma(-m32, q32, fma(-m31, q31, fma(-m30, p30, p33)));
-        const bool ok3 = e3 > s.dtol[K + 3];
-        const double d3 = ok3 ? e3 : 1.0, rd3 = rcp_refined(d3);
+        const double d3 = fma(-m32, q32, fma(-m31, q31, fma(-m30, p30, p33))), rd3 = rcp_refined(d3);
+        const bool ok3 = d3 > s.dtol[K + 3];
         if (bad == 0) bad = !ok0 ? K + 1 : (!ok1 ? K + 2 : (!ok2 ? K + 3 : (!ok3 ? K + 4 : 0)));
 #ifdef PANEL_DEBUG
         if (K == 40 && threadIdx.x == 0) {
-            panel_debug[0] = p00; panel_debug[1] = e1; panel_debug[2] = e2; panel_debug[3] = e3;
+            panel_debug[0] = d0; panel_debug[1] = d1; panel_debug[2] = d2; panel_debug[3] = d3;
             panel_debug[4] = s.dtol[K]; panel_debug[5] = s.dtol[K + 1]; panel_debug[6] = s.dtol[K + 2]; panel_debug[7] = s.dtol[K + 3];
             panel_debug[8] = ok0; panel_debug[9] = ok1; panel_debug[10] = ok2; panel_debug[11] = ok3; panel_debug[12] = bad;
         }

@@ -110,10 +110,10 @@ def test_c_abi_host_entry_points(ctx):
     out = np.empty((70, 45))
     _lib.check(ctx.lib.mgpi_cov_matrix(ctx.handle, x1.ctypes.data, 70, x2.ctypes.data, 45, 3, desc, n, out.ctypes.data))
     ref = oracle.x2cov([oracle.term_se(1.2, 0.3, 0.4, 0.5), oracle.term_white(0.1)], x1, x2)
-    np.testing.assert_allclose(out, ref, rtol=5e-14)
+    np.testing.assert_allclose(out, ref, rtol=1e-15)
     sym = np.empty((70, 70))
     _lib.check(ctx.lib.mgpi_cov_matrix(ctx.handle, x1.ctypes.data, 70, None, 0, 3, desc, n, sym.ctypes.data))
-    np.testing.assert_allclose(sym, oracle.x2cov([oracle.term_se(1.2, 0.3, 0.4, 0.5), oracle.term_white(0.1)], x1, x1), rtol=5e-14)
+    np.testing.assert_allclose(sym, oracle.x2cov([oracle.term_se(1.2, 0.3, 0.4, 0.5), oracle.term_white(0.1)], x1, x1), rtol=1e-15)
     # bad arguments come back as negative statuses with a message, never a crash
     assert ctx.lib.mgpi_cov_matrix(ctx.handle, x1.ctypes.data, 70, x2.ctypes.data, 45, 99, desc, n, out.ctypes.data) < 0
     assert 'd=99' in _lib.last_error()
