@@ -140,6 +140,14 @@ int  mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet);
 int  mgpi_potrs_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* B);
 /* host convenience: b (n, nrhs) row-major host in, x out (may alias) */
 int  mgpi_potrs(mgpi_ctx* ctx, const mgpi_mat* L, const double* b, int64_t n, int nrhs, double* x);
+/* Interpolator.loglikelihood (interpolators.py:331-343) for `batch` kernel parameter sets at once, x and f resident:
+ * terms holds batch * nterms descriptions (problem b: terms[b * nterms .. ]), every problem the same summand structure.
+ * out[b] = -1/2 f^T K_b^-1 f - 1/2 logdet K_b - n/2 log 2 pi.  A K_b that is not positive definite gives out[b] = -inf and
+ * info[b] = its failing pivot (info may be NULL) without disturbing the other members.  This is the inner loop of
+ * optimize_kernel / sample_kernel (:369-387, :474-478, :513-514, :587-601): for n <= 4096 all problems share every launch
+ * (one kernel-matrix launch, n/64 panel-step launches, one reduction); larger n run one after the other. */
+int  mgpi_loglikelihood_batch(mgpi_ctx* ctx, const mgpi_mat* X, const mgpi_mat* f, const mgpi_kernel_desc* terms, int nterms,
+                              int batch, double* out, int32_t* info);
 /* triangular half-solves used by predict_var / rvs:  L X = B  (trans=0)  or  L^T X = B (trans=1) */
 int  mgpi_trsm_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* B, int trans);
 

@@ -85,6 +85,7 @@ _SIGNATURES = {
     'mgpi_potrs_dev': (ctypes.c_int, [_vp, _vp, _vp]),
     'mgpi_potrs': (ctypes.c_int, [_vp, _vp, _vp, c_int64, ctypes.c_int, _vp]),
     'mgpi_trsm_dev': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
+    'mgpi_loglikelihood_batch': (ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(KernelDesc), ctypes.c_int, ctypes.c_int, _vp, _vp]),
     'mgpi_predict_mean_dev': (ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(KernelDesc), ctypes.c_int, _vp, _vp]),
     'mgpi_predict_var_dev': (ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(KernelDesc), ctypes.c_int, _vp, c_int64, _vp]),
     'mgpi_condition_cov_dev': (ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(KernelDesc), ctypes.c_int, _vp, _vp]),
@@ -185,6 +186,21 @@ def make_terms(term_list):
         for k, val in enumerate(lengths):
             arr[i].length[k] = float(val)
     return arr, n
+
+
+def make_terms_batch(term_lists):
+    """[[term, ...] per problem] (every problem the same number of summands) -> (KernelDesc array, nterms, batch)"""
+    nterms = len(term_lists[0])
+    if any(len(tl) != nterms for tl in term_lists):
+        raise ValueError('every member of a batch must have the same number of kernel summands')
+    if not (1 <= nterms <= MAX_TERMS):
+        raise ValueError('a kernel must flatten to between 1 and %d summands (got %d)' % (MAX_TERMS, nterms))
+    arr = (KernelDesc * (nterms * len(term_lists)))()
+    for b, tl in enumerate(term_lists):
+        one, _ = make_terms(tl)
+        for i in range(nterms):
+            arr[b * nterms + i] = one[i]
+    return arr, nterms, len(term_lists)
 
 
 def as_f64(a, ndim=None):

@@ -182,9 +182,15 @@ __global__ __launch_bounds__(256) void potf2_trsm_kernel(double* __restrict__ A,
 __global__ __launch_bounds__(256) void panel_step_kernel(double* __restrict__ A, int64_t lda, int64_t c0, int has_prev, int nfused,
                                                          int rest_cols, int64_t pivot_base, const double* __restrict__ diag0,
                                                          int* __restrict__ info, double* __restrict__ S, double ptol, int mode,
-                                                         double* __restrict__ F) {
+                                                         double* __restrict__ F, int64_t strideA, int64_t strideS, int64_t strideD) {
     __shared__ panel_lds s;
     MGPI_CHAIN_PRIO();
+    // strided batch (mgpi_loglikelihood_batch): problem y = blockIdx.y has its own matrix, scratch strip, original diagonal
+    // and status word; single problems pass a 1-deep grid
+    A += (int64_t)blockIdx.y * strideA;
+    S += (int64_t)blockIdx.y * strideS;
+    diag0 += (int64_t)blockIdx.y * strideD;
+    info += blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     const int64_t cp = c0 - IB, c1 = c0 + IB;
     panel_double4_t acc[4];
@@ -252,13 +258,13 @@ static int launch_panel_step(mgpi_ctx* ctx, double* A, int64_t lda, int64_t c0, 
     double* F = ctx->d_scal + 64;                                          // 64 x 64 + 64 doubles of the ctx's scalar scratch
     if (!split) {
         hipLaunchKernelGGL(panel_step_kernel, dim3((unsigned)(nfused + nrest)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused,
-                           rest_cols, pivot_base, diag0, ctx->d_info, S, ctx->pivot_tol, 0, F);
+                           rest_cols, pivot_base, diag0, ctx->d_info, S, ctx->pivot_tol, 0, F, (int64_t)0, (int64_t)0, (int64_t)0);
     } else {
         hipLaunchKernelGGL(panel_step_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused, rest_cols, pivot_base,
-                           diag0, ctx->d_info, S, ctx->pivot_tol, 1, F);
+                           diag0, ctx->d_info, S, ctx->pivot_tol, 1, F, (int64_t)0, (int64_t)0, (int64_t)0);
         if (nfused - 1 + nrest > 0)
             hipLaunchKernelGGL(panel_step_kernel, dim3((unsigned)(nfused - 1 + nrest)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev,
-                               nfused, rest_cols, pivot_base, diag0, ctx->d_info, S, ctx->pivot_tol, 2, F);
+                               nfused, rest_cols, pivot_base, diag0, ctx->d_info, S, ctx->pivot_tol, 2, F, (int64_t)0, (int64_t)0, (int64_t)0);
     }
     MGPI_HIP_TRY(hipGetLastError());
     return 0;
@@ -685,6 +691,142 @@ extern "C" int mgpi_ctx_status_read(mgpi_ctx* ctx, int64_t* pivot, double* logdi
     MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (pivot) *pivot = info;
     if (logdiag) *logdiag = ld;
+    return 0;
+}
+
+// ---- batched log marginal likelihood at fixed x -------------------------------------------
+// The reference's hyper-parameter loops call loglikelihood once per optimiser step / per walker
+// (mgpi/interpolators.py:369-387, :474-478, :513-514, :587-601): same x, same f, B different kernel parameters, N in the
+// hundreds to low thousands - a regime where one factorisation is a chain of ~N/64 latency-bound launches and the GPU is
+// otherwise empty.  Here B problems share every launch (grid.y / grid.z = problem):
+//   1. B lower kernel matrices in one launch, kernel descriptions read from device memory;
+//   2. f is appended to every matrix as one more row block, so that the panel steps' row substitution leaves
+//      y = L^-1 f in it - no separate triangular solve:  f^T K^-1 f = y^T y;
+//   3. the whole matrix is ONE panel: N/64 launches of panel_step_kernel (deferred right-looking update on MFMA, 64 x 64
+//      Cholesky, substitution), every launch covering all B problems;
+//   4. one launch reduces sum log L_ii and y^T y per problem.
+// A problem whose matrix is not positive definite reports its pivot in info[b] and -inf in out[b]; the others are unaffected.
+#define MGPI_LL_BATCH_MAX_PN 4096
+
+// per problem: diag0 = diagonal of the fresh matrix; rows pn .. pn+63 := [f^T; 0 ...]
+__global__ __launch_bounds__(256) void ll_prepare_kernel(double* __restrict__ A, int64_t lda, int64_t strideA, int64_t n, int64_t pn,
+                                                         const double* __restrict__ f, double* __restrict__ diag0) {
+    double* Ab = A + (int64_t)blockIdx.z * strideA;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;                                         // 0..63: row pn + r; 64: the diagonal
+    if (j >= pn) return;
+    if (r < IB) Ab[(pn + r) * lda + j] = (r == 0 && j < n) ? f[j] : 0.0;
+    else diag0[(int64_t)blockIdx.z * pn + j] = Ab[j * lda + j];
+}
+
+// out[b] = -1/2 y^T y - sum log L_ii - n/2 log(2 pi), or -inf when info[b] != 0; L_ii from the scratch strip
+__global__ __launch_bounds__(256) void ll_finish_kernel(const double* __restrict__ A, int64_t lda, int64_t strideA, int64_t n, int64_t pn,
+                                                        const double* __restrict__ S, const int* __restrict__ info,
+                                                        double* __restrict__ out) {
+    __shared__ double part[2][256];
+    const double* y = A + (int64_t)blockIdx.x * strideA + pn * lda;
+    const double* Sb = S + (int64_t)blockIdx.x * pn * IB;
+    double q = 0.0, l = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        q += y[i] * y[i];
+        l += log(Sb[i * IB + (i % IB)]);
+    }
+    part[0][threadIdx.x] = q;
+    part[1][threadIdx.x] = l;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            part[0][threadIdx.x] += part[0][threadIdx.x + w];
+            part[1][threadIdx.x] += part[1][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        out[blockIdx.x] = (info[blockIdx.x] != 0) ? -INFINITY : -0.5 * part[0][0] - part[1][0] - 0.5 * (double)n * 1.8378770664093453;
+}
+
+extern "C" int mgpi_loglikelihood_batch(mgpi_ctx* ctx, const mgpi_mat* X, const mgpi_mat* f, const mgpi_kernel_desc* terms, int nterms,
+                                        int batch, double* out, int32_t* info) {
+    MGPI_REQUIRE(ctx && X && f && terms && out, "mgpi_loglikelihood_batch: null pointer");
+    MGPI_REQUIRE(batch >= 1 && batch <= 4096, "mgpi_loglikelihood_batch: batch %d outside [1, 4096]", batch);
+    MGPI_REQUIRE(f->rows == X->rows && f->ld == 1, "mgpi_loglikelihood_batch: f must be an (n x 1) vector matching X");
+    const int64_t n = X->rows;
+    const int d = (int)X->cols;
+    const int64_t pn = mgpi_roundup(n, IB);
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<mgpi_terms_dev> tb((size_t)batch);
+    for (int b = 0; b < batch; ++b) MGPI_TRY(mgpi_make_terms(terms + (size_t)b * nterms, nterms, d, &tb[b]));
+    if (pn > MGPI_LL_BATCH_MAX_PN) {
+        // large problems fill the chip on their own: one after the other through the blocked factorisation, x still resident
+        mgpi_mat *K = nullptr, *a = nullptr;
+        int st = mgpi_mat_alloc_wide(ctx, n, n, &K);
+        if (st == 0) st = mgpi_mat_alloc(ctx, n, 1, &a);
+        std::vector<double> fh((size_t)n), ah((size_t)n);
+        if (st == 0) st = mgpi_mat_download(f, fh.data(), 1);
+        for (int b = 0; b < batch && st == 0; ++b) {
+            double logdet = 0.0;
+            st = mgpi_cov_matrix_dev(ctx, X, nullptr, terms + (size_t)b * nterms, nterms, 1, K);
+            if (st == 0) st = mgpi_potrf_dev(ctx, K, &logdet);
+            if (st > 0) {                                   // not positive definite: this member only
+                if (info) info[b] = st;
+                out[b] = -INFINITY;
+                st = 0;
+                continue;
+            }
+            if (st == 0) st = mgpi_mat_copy(ctx, f, a);
+            if (st == 0) st = mgpi_potrs_dev(ctx, K, a);
+            if (st == 0) st = mgpi_mat_download(a, ah.data(), 1);
+            if (st == 0) {
+                double q = 0.0;
+                for (int64_t i = 0; i < n; ++i) q += fh[i] * ah[i];
+                out[b] = -0.5 * q - 0.5 * logdet - 0.5 * (double)n * 1.8378770664093453;
+                if (info) info[b] = 0;
+            }
+        }
+        mgpi_mat_free(K);
+        mgpi_mat_free(a);
+        return st;
+    }
+    const int64_t lda = mgpi_roundup(pn, MGPI_TILE);
+    const int64_t strideA = (pn + IB) * lda;
+    const size_t bytesA = (size_t)batch * strideA * sizeof(double);
+    const size_t bytesS = (size_t)batch * pn * IB * sizeof(double);
+    const size_t bytesD = (size_t)batch * pn * sizeof(double);
+    const size_t bytesT = mgpi_roundup((int64_t)(batch * sizeof(mgpi_terms_dev)), 256);
+    const size_t bytesO = mgpi_roundup((int64_t)(batch * sizeof(double)), 256), bytesI = mgpi_roundup((int64_t)(batch * sizeof(int)), 256);
+    double* blk = nullptr;
+    size_t got = 0;
+    MGPI_TRY(mgpi_pool_alloc(ctx, bytesA + bytesS + bytesD + bytesT + bytesO + bytesI, &blk, &got));
+    struct release { mgpi_ctx* c; double* p; size_t b; ~release() { mgpi_pool_free(c, p, b); } } guard{ctx, blk, got};
+    char* wptr = (char*)blk;
+    double* A = (double*)wptr;             wptr += bytesA;
+    double* S = (double*)wptr;             wptr += bytesS;
+    double* D0 = (double*)wptr;            wptr += bytesD;
+    mgpi_terms_dev* T = (mgpi_terms_dev*)wptr;  wptr += bytesT;
+    double* O = (double*)wptr;             wptr += bytesO;
+    int* I = (int*)wptr;
+    MGPI_HIP_TRY(hipMemcpyAsync(T, tb.data(), (size_t)batch * sizeof(mgpi_terms_dev), hipMemcpyHostToDevice, ctx->stream));
+    MGPI_HIP_TRY(hipMemsetAsync(I, 0, (size_t)batch * sizeof(int), ctx->stream));
+    MGPI_TRY(mgpi_launch_cov_batch(ctx, T, d, X->d, X->ld, n, pn, A, lda, strideA, batch));
+    hipLaunchKernelGGL(ll_prepare_kernel, dim3((unsigned)((pn + 255) / 256), IB + 1, (unsigned)batch), dim3(256), 0, ctx->stream, A, lda,
+                       strideA, n, pn, f->d, D0);
+    for (int64_t c0 = 0; c0 < pn; c0 += IB) {
+        const int has_prev = c0 > 0;
+        const int nfused = (int)(1 + (pn + IB - c0 - IB) / IB);            // the f block is one more row block below
+        const int rest_cols = has_prev ? (int)((pn - c0 - IB) / IB) : 0;
+        int64_t nrest = 0;
+        for (int tj = 0; tj < rest_cols; ++tj) nrest += nfused - 1 - tj;
+        hipLaunchKernelGGL(panel_step_kernel, dim3((unsigned)(nfused + nrest), (unsigned)batch), dim3(256), 0, ctx->stream, A, lda, c0,
+                           has_prev, nfused, rest_cols, c0, D0 + c0, I, S + c0 * IB, ctx->pivot_tol, 0, (double*)nullptr, strideA,
+                           pn * IB, pn);
+    }
+    hipLaunchKernelGGL(ll_finish_kernel, dim3((unsigned)batch), dim3(256), 0, ctx->stream, A, lda, strideA, n, pn, S, I, O);
+    MGPI_HIP_TRY(hipGetLastError());
+    MGPI_HIP_TRY(hipMemcpyAsync(out, O, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<int> ih((size_t)batch);
+    MGPI_HIP_TRY(hipMemcpyAsync(ih.data(), I, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (info) for (int b = 0; b < batch; ++b) info[b] = ih[b];
     return 0;
 }
 

@@ -59,6 +59,74 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(mgpi_terms_dev t, const d
     }
 }
 
+// Strided batch of LOWER kernel matrices over ONE coordinate table: problem z = blockIdx.z uses the kernel description
+// tb[z] (device memory) and writes out + z * stride.  The hyper-parameter loops of the reference evaluate the
+// likelihood of 2 * num_dim walkers per step at fixed x (mgpi/interpolators.py:513-514, closure at :369-387).
+template <int D>
+__global__ __launch_bounds__(256) void cov_tile_batch_kernel(const mgpi_terms_dev* __restrict__ tb, const double* __restrict__ x,
+                                                             int64_t ldx, int64_t n, double* __restrict__ out, int64_t ldo,
+                                                             int64_t stride) {
+    constexpr int DD = (D > 0) ? D : MGPI_MAX_D;
+    __shared__ double s1[DD][COV_T];
+    __shared__ __attribute__((aligned(16))) double s2[DD][COV_T];
+    const mgpi_terms_dev& t = tb[blockIdx.z];
+    const int nd = (D > 0) ? D : t.d;
+    const int64_t row0 = (int64_t)blockIdx.y * COV_T, col0 = (int64_t)blockIdx.x * COV_T;
+    if (col0 > row0) return;
+    out += (int64_t)blockIdx.z * stride;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < COV_T * nd; idx += 256) {
+        const int r = idx / nd, k = idx - r * nd;
+        s1[k][r] = (row0 + r < n) ? x[(row0 + r) * ldx + k] : 0.0;
+        s2[k][r] = (col0 + r < n) ? x[(col0 + r) * ldx + k] : 0.0;
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    double a[4][DD], b[4][DD];
+#pragma unroll
+    for (int k = 0; k < DD; ++k) {
+        if (k < nd) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r][k] = s1[k][ty * 4 + r];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const double2 v = *reinterpret_cast<const double2*>(&s2[k][2 * tx + 32 * c]);
+                b[2 * c][k] = v.x;
+                b[2 * c + 1][k] = v.y;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = row0 + ty * 4 + r;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int64_t j = col0 + 2 * tx + 32 * c;
+            double2 v;
+            v.x = mgpi_cov_entry<D>(t, a[r], b[2 * c]);
+            v.y = mgpi_cov_entry<D>(t, a[r], b[2 * c + 1]);
+            if (i >= n || j >= n) v.x = (i == j) ? 1.0 : 0.0;               // unit diagonal in the padding
+            if (i >= n || j + 1 >= n) v.y = (i == j + 1) ? 1.0 : 0.0;
+            *reinterpret_cast<double2*>(&out[i * ldo + j]) = v;
+        }
+    }
+}
+
+int mgpi_launch_cov_batch(mgpi_ctx* ctx, const mgpi_terms_dev* tb_dev, int d, const double* x, int64_t ldx, int64_t n, int64_t pn,
+                          double* out, int64_t ldo, int64_t stride, int batch) {
+    MGPI_REQUIRE(pn % COV_T == 0 && batch >= 1 && batch < 65536, "cov batch: pn=%lld batch=%d", (long long)pn, batch);
+    dim3 grid((unsigned)(pn / COV_T), (unsigned)(pn / COV_T), (unsigned)batch), block(256);
+    switch (d) {
+        case 1: hipLaunchKernelGGL(cov_tile_batch_kernel<1>, grid, block, 0, ctx->stream, tb_dev, x, ldx, n, out, ldo, stride); break;
+        case 2: hipLaunchKernelGGL(cov_tile_batch_kernel<2>, grid, block, 0, ctx->stream, tb_dev, x, ldx, n, out, ldo, stride); break;
+        case 3: hipLaunchKernelGGL(cov_tile_batch_kernel<3>, grid, block, 0, ctx->stream, tb_dev, x, ldx, n, out, ldo, stride); break;
+        case 4: hipLaunchKernelGGL(cov_tile_batch_kernel<4>, grid, block, 0, ctx->stream, tb_dev, x, ldx, n, out, ldo, stride); break;
+        default: hipLaunchKernelGGL(cov_tile_batch_kernel<0>, grid, block, 0, ctx->stream, tb_dev, x, ldx, n, out, ldo, stride);
+    }
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void cov_paired_kernel(mgpi_terms_dev t, const double* __restrict__ x1,
                                                          const double* __restrict__ x2, int64_t p,

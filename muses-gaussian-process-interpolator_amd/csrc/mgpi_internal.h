@@ -135,6 +135,9 @@ int mgpi_launch_cov(mgpi_ctx* ctx, const mgpi_terms_dev& t,
                     int symmetric, int lower_only, int pad_identity,
                     double* out, int64_t ldo);
 
+int mgpi_launch_cov_batch(mgpi_ctx* ctx, const mgpi_terms_dev* tb_dev, int d, const double* x, int64_t ldx, int64_t n, int64_t pn,
+                          double* out, int64_t ldo, int64_t stride, int batch);
+
 // panel pieces of the Cholesky (chol.hip)
 int mgpi_launch_potf2(mgpi_ctx* ctx, double* A, int64_t lda, int64_t pivot_base, const double* diag0);   // 64x64 in place
 int mgpi_launch_trsm_rows(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double* A, int64_t lda, int64_t rows);

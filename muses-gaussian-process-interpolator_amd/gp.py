@@ -327,10 +327,44 @@ class Interpolator(HyperParameterSearch):
 
     def loglikelihood(self, source_x, source_f, verbose=False):
         """log marginal likelihood of source_f = f(source_x) under the zero-mean process"""
-        try:
-            gp = self.fit(source_x, source_f, verbose=verbose)
-        except _lib.NotPositiveDefinite:
+        value, pivot = self.loglikelihoods(source_x, source_f, [np.array(self.kernel.params, dtype=float)], verbose=verbose)
+        if pivot[0] != 0:
             raise AssertionError('covariance is not positive definite!')       # interpolators.py:340
+        return float(value[0])
+
+    def resident(self, source_x, source_f):
+        """(X, f) uploaded once, for repeated loglikelihoods() calls at fixed data: what the closure of the reference's
+        hyper-parameter search holds on to (interpolators.py:369-387)"""
+        x = _points(source_x)
         f = _lib.as_f64(source_f).reshape(-1)
-        alpha = gp.alpha.to_host().reshape(-1)
-        return -0.5 * (f @ alpha) - 0.5 * gp.logdet - 0.5 * len(f) * np.log(2 * np.pi)
+        assert len(f) == len(x), 'source_f has %d entries for %d source points' % (len(f), len(x))
+        return _lib.DeviceMatrix.from_host(self.context, x), _lib.DeviceMatrix.from_host(self.context, f)
+
+    def loglikelihoods(self, source_x, source_f, kernel_params, resident=None, verbose=False):
+        """additive: the log marginal likelihood for EVERY row of kernel_params (kernel parameter vectors in kernel
+        order, like Kernel.update(*row)) in one device call - the walkers of sample_kernel, the probes of
+        optimize_kernel.  Returns (values (B,), pivots (B,)): a parameter set whose covariance is not positive definite
+        gets -inf and its failing pivot, the others are unaffected.  The kernel's own parameters are left as they were.
+        `resident` = self.resident(source_x, source_f) skips the upload of x and f."""
+        rows = np.atleast_2d(np.asarray(kernel_params, dtype=float))
+        X, F = resident if resident is not None else self.resident(source_x, source_f)
+        ctx = self.context
+        keep = np.array(self.kernel.params, dtype=float)
+        try:
+            term_lists = []
+            for row in rows:
+                self.kernel.update(*row)
+                term_lists.append(_flatten(self.kernel, self.nugget))
+        finally:
+            self.kernel.update(*keep)
+        desc, nterms, batch = _lib.make_terms_batch(term_lists)
+        out = np.empty(batch, dtype=np.float64)
+        info = np.zeros(batch, dtype=np.int32)
+        if verbose:
+            print('computing %d loglikelihood%s of %d samples' % (batch, '' if batch == 1 else 's', X.rows))
+            t0 = time.time()
+        _lib.check(ctx.lib.mgpi_loglikelihood_batch(ctx.handle, X.handle, F.handle, desc, nterms, batch, out.ctypes.data,
+                                                    info.ctypes.data))
+        if verbose:
+            print('    time : %.6f sec' % (time.time() - t0))
+        return out, info

@@ -34,22 +34,47 @@ class LogPosterior(object):
         if fixed:
             interp.update(**fixed)
         self.free = [name for name in interp.kernel._params if name not in fixed]
+        self._resident = None          # (X, f) on the device, uploaded on first use
 
     def __call__(self, params):
+        """one parameter vector -> float; a (B, num_dim) array -> (B,) array in ONE device call (emcee's vectorize=True:
+        the 2 * num_dim walkers of interpolators.py:513-514 are evaluated together, x and f resident on the GPU)"""
         params = np.asarray(params, dtype=float)
-        if np.any(params <= 0) or np.any(params != params):
-            return -np.inf
-        self.interp.update(**dict(zip(self.free, params)))
-        logp = self.logprior(params)
-        if logp == -np.inf:
-            return -np.inf
-        try:
-            logl = self.interp.loglikelihood(self.source_x, self.source_f, **self.kwargs) / self.temperature
-        except AssertionError:          # not positive definite at these parameters: an excluded point
-            return -np.inf
-        if self.verbose:
-            print('>>> %s\n  logl=%.6e\n  logp=%.6e' % (self.interp.kernel, logl, logp))
-        return logl + logp
+        if params.ndim == 2:
+            return self.many(params)
+        return float(self.many(params[None, :])[0])
+
+    def many(self, params):
+        params = np.asarray(params, dtype=float)
+        out = np.full(len(params), -np.inf)
+        logp = np.zeros(len(params))
+        todo = []
+        for i, row in enumerate(params):
+            if np.any(row <= 0) or np.any(row != row):             # interpolators.py:371-372
+                continue
+            logp[i] = self.logprior(row)
+            if logp[i] == -np.inf:
+                continue
+            todo.append(i)
+        if not todo:
+            return out
+        if self._resident is None:
+            self._resident = self.interp.resident(self.source_x, self.source_f)
+        # full kernel parameter vectors: the fixed ones at their values, the free ones from the rows
+        names = list(self.interp.kernel._params)
+        base = np.array(self.interp.kernel.params, dtype=float)
+        cols = [names.index(name) for name in self.free]
+        rows = np.tile(base, (len(todo), 1))
+        rows[:, cols] = params[todo]
+        logl, pivot = self.interp.loglikelihoods(self.source_x, self.source_f, rows, resident=self._resident, **self.kwargs)
+        for j, i in enumerate(todo):
+            if pivot[j] == 0:          # not positive definite at these parameters: an excluded point
+                out[i] = logl[j] / self.temperature + logp[i]
+                if self.verbose:
+                    print('>>> %s\n  logl=%.6e\n  logp=%.6e' % (rows[j], logl[j] / self.temperature, logp[i]))
+        if len(todo) == 1 and len(params) == 1:
+            self.interp.update(**dict(zip(self.free, params[0])))      # a single evaluation leaves the kernel there, as upstream
+        return out
 
 
 def initial_points(interp, logprior=None, fixed=None, size=1, verbose=False, rng=None):
@@ -111,7 +136,7 @@ class HyperParameterSearch(object):
                       num_burnin=DEFAULT_NUM_BURNIN, num_samples=DEFAULT_NUM_SAMPLES, num_walkers=DEFAULT_NUM_WALKERS,
                       verbose=False, Verbose=False):
         """MCMC over the free kernel parameters with emcee's EnsembleSampler (interpolators.py:491-610);
-        returns (samples (num_samples*num_walkers, num_dim), logprob values, sampler)"""
+        returns (samples (num_samples, num_walkers, num_dim), logprob (num_samples, num_walkers), sampler)"""
         try:
             import emcee
         except ImportError:
@@ -122,12 +147,14 @@ class HyperParameterSearch(object):
         if num_walkers is None:
             num_walkers = 2 * num_dim
         state = self._construct_initial_params(logprior=logprior, fixed=fixed, size=num_walkers, verbose=Verbose)
-        sampler = emcee.EnsembleSampler(num_walkers, num_dim, logprob)
+        # vectorize=True: emcee hands over all walkers of a half-step at once -> one batched device call
+        sampler = emcee.EnsembleSampler(num_walkers, num_dim, logprob, vectorize=True)
         if verbose:
             print('running sampler for %d steps of burn-in' % num_burnin)
-        state = sampler.run_mcmc(state, num_burnin)
+        state = sampler.run_mcmc(state, num_burnin, progress=Verbose)
         sampler.reset()
         if verbose:
             print('running sampler for %d steps' % num_samples)
-        sampler.run_mcmc(state, num_samples)
-        return sampler.get_chain(flat=True), sampler.get_log_prob(flat=True), sampler
+        sampler.run_mcmc(state, num_samples, progress=Verbose)
+        # (num_samples, num_walkers, num_dim) and (num_samples, num_walkers), unflattened like interpolators.py:606-609
+        return sampler.get_chain(), sampler.get_log_prob(), sampler

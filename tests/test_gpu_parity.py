@@ -419,3 +419,86 @@ def test_matern_order_limits():
     for bad in [0.0, -1.0, 120.5, np.nan]:
         with pytest.raises((ValueError, RuntimeError, AssertionError)):
             mgpi.MaternKernel(bad, 1.0, 1.0).cov(np.zeros((1, 1)), np.ones((1, 1)))
+
+
+def test_loglikelihood_batch_matches_single_calls_and_golden():
+    """mgpi_loglikelihood_batch: every member equals the single-call value and the
+    reference's own loglikelihood (rtol 1e-10, cond-scaled like the mean); a member that is not positive definite
+    returns -inf with its pivot and leaves the others untouched; the kernel's parameters are restored"""
+    for name in ('toy_n64_d2_nugget', 'toy_multiterm', 'c1_n512_d2', 'uiuc_checkerboard_nugget', 'sceos_3d'):
+        assert name in NAMES
+        g = load_golden(name)
+        kernel, nugget = product_kernel(g, 'kernel'), product_kernel(g, 'nugget')
+        it = mgpi.Interpolator(kernel, nugget=nugget)
+        base = np.array(kernel.params, dtype=float)
+        rows = np.array([base, base * 1.1, base * 0.9, base * np.linspace(0.8, 1.2, len(base))])
+        vals, piv = it.loglikelihoods(g['x'], g['f'], rows)
+        assert np.array_equal(np.array(kernel.params, dtype=float), base) and np.all(piv == 0)
+        tol = max(1e-10, 4e-17 * float(g['cond_K']))
+        assert abs(vals[0] - float(g['loglike'])) < tol * abs(float(g['loglike']))
+        for row, v in zip(rows, vals):
+            kernel.update(*row)
+            ref = oracle.loglikelihood(oracle_terms_of(kernel), oracle_terms_of(nugget), g['x'], g['f'])
+            assert abs(v - ref) < max(tol, 1e-9) * abs(ref)
+        kernel.update(*base)
+
+
+def oracle_terms_of(k):
+    if k is None:
+        return []
+    out = []
+    for kind, sigma, lengths in [(t[0], t[1], t[2]) for t in k.terms()]:
+        out.append(oracle.term_se(sigma, *lengths) if kind == 0 else oracle.term_white(sigma))
+    return out
+
+
+@pytest.mark.parametrize('n,d', [(1, 1), (63, 2), (64, 2), (65, 3), (338, 2), (1311, 2), (2050, 3)])
+def test_loglikelihood_batch_sizes_and_failures(n, d):
+    rng = np.random.default_rng(n)
+    x = rng.random((n, d))
+    f = np.sin(3 * x[:, 0]) + 0.1 * rng.standard_normal(n)
+    k = mgpi.SquaredExponentialKernel(1.0, *([0.2] * d)) + mgpi.WhiteNoiseKernel(0.05)
+    it = mgpi.Interpolator(k)
+    base = np.array(k.params, dtype=float)
+    good = [base, base * 1.3, base * 0.7]
+    res = it.resident(x, f)
+    vals, piv = it.loglikelihoods(x, f, good, resident=res)
+    for row, v in zip(good, vals):
+        ref = oracle.loglikelihood([oracle.term_se(row[0], *row[1:1 + d]), oracle.term_white(row[1 + d])], [], x, f)
+        assert abs(v - ref) <= 1e-10 * max(1.0, abs(ref)) * (1 + n / 500.0)
+    assert np.all(piv == 0)
+    # single call == member of the batch, bit for bit (same kernels)
+    assert it.loglikelihood(x, f) == vals[0]
+    if n >= 20:
+        # one member with no noise and length scales far beyond the data's extent: K is numerically rank deficient for
+        # that member only (its pivots fall below the tolerance)
+        singular = base.copy()
+        singular[1:1 + d] *= 300.0
+        singular[-1] = 0.0
+        vals2, piv2 = it.loglikelihoods(x, f, [base, singular, base * 1.3], resident=res)
+        assert vals2[0] == vals[0] and vals2[2] == vals[1] and vals2[1] == -np.inf
+        assert piv2[0] == 0 and piv2[2] == 0 and 1 <= piv2[1] <= n
+        k.update(*singular)
+        try:
+            with pytest.raises(AssertionError):
+                it.loglikelihood(x, f)
+        finally:
+            k.update(*base)
+
+
+def test_logposterior_vectorised_call():
+    """LogPosterior on a (B, num_dim) array (emcee's vectorize=True): one device call, invalid rows -inf"""
+    from mgpi_amd.hyper import LogPosterior
+    rng = np.random.default_rng(5)
+    x = rng.random((200, 2))
+    f = np.sin(4 * x[:, 0]) + x[:, 1]
+    k = mgpi.SquaredExponentialKernel(1.0, 0.3, 0.3) + mgpi.WhiteNoiseKernel(0.05)
+    it = mgpi.Interpolator(k)
+    lp = LogPosterior(it, x, f, fixed={'sigma_1': 0.05}, temperature=2.0)
+    pts = np.array([[1.0, 0.3, 0.3], [-1.0, 0.3, 0.3], [1.2, 0.25, 0.4], [np.nan, 1, 1]])
+    got = lp(pts)
+    assert got.shape == (4,) and got[1] == -np.inf and got[3] == -np.inf
+    for i in (0, 2):
+        assert abs(got[i] - lp(pts[i])) < 1e-12 * abs(got[i])
+        ref = oracle.loglikelihood([oracle.term_se(pts[i][0], pts[i][1], pts[i][2]), oracle.term_white(0.05)], [], x, f) / 2.0
+        assert abs(got[i] - ref) < 1e-10 * abs(ref)

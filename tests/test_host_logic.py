@@ -184,3 +184,55 @@ def test_logposterior_guards_without_touching_the_gpu():
     pts = initial_points(it, fixed={'sigma': 1.0}, size=4, rng=np.random.default_rng(0))
     assert pts.shape == (4, 2)
     assert hasattr(it, 'optimize_kernel') and hasattr(it, 'sample_kernel')
+
+
+def test_utils_mirror_the_reference():
+    """construct_logprior / subdivide_data / seed (mgpi/utils.py:11-16,30-73), pure numpy"""
+    lp = mgpi.construct_logprior(('sigma', 'length0', 'length1'), {'sigma': (0.1, 2.0), 'length1': (1.0, 3.0)}, fixed={'length0': 0.5})
+    assert lp([1.0, 2.0]) == 0.0 and lp([3.0, 2.0]) == -np.inf and lp([1.0, 0.5]) == -np.inf
+    with pytest.raises(AssertionError):
+        mgpi.construct_logprior(('sigma',), {'nope': (0, 1)}, fixed={})
+    mgpi.seed(7)
+    x, f = np.arange(20.0).reshape(10, 2), np.arange(10.0)
+    (xa, fa), (xb, fb) = mgpi.subdivide_data(x, f, frac=0.3)
+    assert len(xa) == 3 and len(xb) == 7 and sorted(np.concatenate([fa, fb])) == list(f)
+    assert np.array_equal(xa[:, 0] / 2, fa)
+    mgpi.seed(7)
+    (xa2, _), _ = mgpi.subdivide_data(x, f, frac=0.3)
+    assert np.array_equal(xa, xa2)
+
+
+def test_sample_kernel_returns_the_reference_layout(monkeypatch):
+    """sample_kernel returns sampler.get_chain() / get_log_prob() UNflattened, (num_samples, num_walkers,
+    num_dim) and (num_samples, num_walkers), and forwards progress=Verbose (interpolators.py:587-609).  emcee is not
+    importable here, so a stub sampler stands in; the log-probability is never evaluated (no GPU)."""
+    import sys
+    import types
+    calls = []
+
+    class StubSampler(object):
+        def __init__(self, nwalkers, ndim, fn, vectorize=False):
+            self.nwalkers, self.ndim, self.vectorize, self.steps = nwalkers, ndim, vectorize, 0
+
+        def run_mcmc(self, state, nsteps, progress=False):
+            calls.append((nsteps, progress))
+            self.steps = nsteps
+            return state
+
+        def reset(self):
+            self.steps = 0
+
+        def get_chain(self, flat=False):
+            assert not flat
+            return np.zeros((self.steps, self.nwalkers, self.ndim))
+
+        def get_log_prob(self, flat=False):
+            assert not flat
+            return np.zeros((self.steps, self.nwalkers))
+
+    monkeypatch.setitem(sys.modules, 'emcee', types.SimpleNamespace(EnsembleSampler=StubSampler))
+    it = mgpi.Interpolator(mgpi.SquaredExponentialKernel(1.0, 0.5, 0.7))
+    np.random.seed(0)
+    chain, logp, sampler = it.sample_kernel(np.zeros((4, 2)), np.zeros(4), fixed={'sigma': 1.0}, num_burnin=3, num_samples=5, Verbose=True)
+    assert chain.shape == (5, 4, 2) and logp.shape == (5, 4)          # num_walkers defaults to 2 * num_dim = 4
+    assert calls == [(3, True), (5, True)] and sampler.vectorize
