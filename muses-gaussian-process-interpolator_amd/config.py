@@ -28,7 +28,8 @@ from .gp import Interpolator
 from .kernel_objects import CombinedKernel, Kernel
 from .utils import factory
 
-__all__ = ['parse_table', 'parse_kernel_section', 'parse_interpolator', 'load_data', 'load_ascii_data', 'save_ascii_data']
+__all__ = ['parse_table', 'parse_kernel_section', 'parse_interpolator', 'load_data', 'load_ascii_data', 'save_ascii_data',
+           'load_target_data', 'save_compressed_data', 'load_compressed_data', 'save_conditioned_data', 'load_conditioned_data']
 
 TYPE, PATH, X_COLUMNS, F_COLUMN, PRIOR, DOWNSAMPLE = 'type', 'path', 'x_columns', 'f_column', 'prior', 'downsample'
 INTERPOLATOR, KERNEL, NUGGET = 'Interpolator', 'kernel', 'nugget'
@@ -217,3 +218,106 @@ def parse_interpolator(path, verbose=False):
         if nugget is not None:
             print('  nugget = %s' % nugget)
     return klass(kernel, nugget=nugget, **kwargs)
+
+
+#-------------------------------------------------
+# containers: the saved model (compressed data) and the conditioned output (mgpi/io.py:284-387)
+#
+# The reference writes HDF files with h5py.  The field names and shapes below are the reference's; the container is
+#   * HDF (suffix .h5 / .hdf / .hdf5) when h5py is importable - files then interoperate with the reference's tools -
+#     ImportError otherwise, as upstream;
+#   * an ``.npz`` mirror with the same field names (numpy.load without pickle) - always available.
+
+def _is_npz(path):
+    return str(path).endswith('.npz')
+
+
+def _h5py():
+    try:
+        import h5py
+    except ImportError:
+        raise ImportError('could not import h5py')        # io.py:297
+    return h5py
+
+
+def load_target_data(path, xcols, verbose=False):
+    """the target_x grid from a table file: (M, len(xcols)) in the order of xcols (io.py:284-290)"""
+    data = load_data(path, verbose=verbose)
+    for col in xcols:
+        assert col in data.dtype.names, 'required column=%s missing in %s' % (col, path)
+    return np.transpose([data[col] for col in xcols])
+
+
+def save_compressed_data(path, source_x, compressed, params, xcols=None, fcol='f', verbose=False):
+    """fcol, xcols, source_x (N, D), params (P, num_params), compressed (P, N)   (io.py:317-338)"""
+    if verbose:
+        print('saving %d compressed datasets into: %s' % (len(compressed), path))
+    source_x = np.asarray(source_x, dtype=float)
+    nsmp, ndim = source_x.shape
+    if xcols is None:
+        xcols = ['x%d' % dim for dim in range(ndim)]
+    fields = dict(fcol=str(fcol), xcols=[str(c) for c in xcols], source_x=source_x, params=np.asarray(params, dtype=float),
+                  compressed=np.asarray(compressed, dtype=float))
+    if _is_npz(path):
+        np.savez(path, **fields)
+        return
+    with _h5py().File(path, 'w') as obj:
+        for name, val in fields.items():
+            obj.create_dataset(name=name, data=val)
+
+
+def load_compressed_data(path, verbose=False):
+    """-> source_x, compressed, params, xcols, fcol   (io.py:294-313)"""
+    if verbose:
+        print('loading compressed datasets from: ' + path)
+    if _is_npz(path):
+        with np.load(path, allow_pickle=False) as obj:
+            fcol, xcols = str(obj['fcol']), [str(c) for c in obj['xcols']]
+            source_x, params, compressed = obj['source_x'], obj['params'], obj['compressed']
+    else:
+        with _h5py().File(path, 'r') as obj:
+            fcol = obj['fcol'][()]
+            xcols = [c.decode() if isinstance(c, bytes) else str(c) for c in obj['xcols'][:]]
+            source_x, params, compressed = obj['source_x'][:], obj['params'][:], obj['compressed'][:]
+            fcol = fcol.decode() if isinstance(fcol, bytes) else str(fcol)
+    if verbose:
+        print('found %d compressed datasets for %d source_x (%s)' % (len(compressed), len(source_x), ', '.join(xcols)))
+    return source_x, compressed, params, xcols, fcol
+
+
+def save_conditioned_data(path, target_x, mean, cov=None, xcols=None, fcol='f', verbose=False):
+    """fcol, xcols, target_x (M, D), mean (M,), optionally cov   (io.py:365-387)"""
+    target_x = np.asarray(target_x, dtype=float)
+    nsmp, ndim = target_x.shape
+    if verbose:
+        print('saving conditioned mean, cov for %d locations into: %s' % (nsmp, path))
+    if xcols is None:
+        xcols = ['x%d' % dim for dim in range(ndim)]
+    fields = dict(fcol=str(fcol), xcols=[str(c) for c in xcols], target_x=target_x, mean=np.asarray(mean, dtype=float))
+    if cov is not None:
+        fields['cov'] = np.asarray(cov, dtype=float)
+    if _is_npz(path):
+        np.savez(path, **fields)
+        return
+    with _h5py().File(path, 'w') as obj:
+        for name, val in fields.items():
+            obj.create_dataset(name=name, data=val)
+
+
+def load_conditioned_data(path, verbose=False):
+    """-> mean, cov (None when absent), target_x, xcols, fcol   (io.py:342-361)"""
+    if verbose:
+        print('loading conditioned mean, cov from: ' + path)
+    if _is_npz(path):
+        with np.load(path, allow_pickle=False) as obj:
+            fcol, xcols = str(obj['fcol']), [str(c) for c in obj['xcols']]
+            target_x, mean = obj['target_x'], obj['mean']
+            cov = obj['cov'] if 'cov' in obj.files else None
+    else:
+        with _h5py().File(path, 'r') as obj:
+            fcol = obj['fcol'][()]
+            fcol = fcol.decode() if isinstance(fcol, bytes) else str(fcol)
+            xcols = [c.decode() if isinstance(c, bytes) else str(c) for c in obj['xcols'][:]]
+            target_x, mean = obj['target_x'][:], obj['mean'][:]
+            cov = obj['cov'][:] if ('cov' in obj.keys()) else None
+    return mean, cov, target_x, xcols, fcol

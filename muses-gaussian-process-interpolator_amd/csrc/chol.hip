@@ -197,10 +197,8 @@ __global__ __launch_bounds__(256) void panel_step_kernel(double* __restrict__ A,
     const int first_fused = (mode == 2) ? 1 : 0;                 // mode 2 has no workgroup for the diagonal block's rows
     if ((int)blockIdx.x + first_fused >= nfused) {
         // update role: tile (ti, tj) of the rows >= c1, column blocks c1 + 64 tj (tj < rest_cols); only tiles on/below the diagonal
-        int t = (int)blockIdx.x + first_fused - nfused, tj = 0;
-        const int nrows1 = nfused - 1;
-        while (t >= nrows1 - tj) { t -= nrows1 - tj; ++tj; }
-        const int ti = tj + t;
+        int ti, tj;
+        panel_rest_decode((int)blockIdx.x + first_fused - nfused, nfused - 1, ti, tj);
         double* C = A + (c1 + (int64_t)IB * ti) * lda + c1 + (int64_t)IB * tj;
         panel_load(acc, C, lda, w, g, c, false);
         panel_gemm_nt(acc, A + (c1 + (int64_t)IB * ti + 16 * w + c) * lda + cp + 2 * g, A + (c1 + (int64_t)IB * tj + c) * lda + cp + 2 * g, lda, 0, 4);
@@ -710,10 +708,12 @@ extern "C" int mgpi_ctx_status_read(mgpi_ctx* ctx, int64_t* pivot, double* logdi
 
 // per problem: diag0 = diagonal of the fresh matrix; rows pn .. pn+63 := [f^T; 0 ...]
 __global__ __launch_bounds__(256) void ll_prepare_kernel(double* __restrict__ A, int64_t lda, int64_t strideA, int64_t n, int64_t pn,
-                                                         const double* __restrict__ f, double* __restrict__ diag0) {
+                                                         const double* __restrict__ f, double* __restrict__ diag0,
+                                                         int* __restrict__ info) {
     double* Ab = A + (int64_t)blockIdx.z * strideA;
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int r = blockIdx.y;                                         // 0..63: row pn + r; 64: the diagonal
+    if (j == 0 && r == 0) info[blockIdx.z] = 0;
     if (j >= pn) return;
     if (r < IB) Ab[(pn + r) * lda + j] = (r == 0 && j < n) ? f[j] : 0.0;
     else diag0[(int64_t)blockIdx.z * pn + j] = Ab[j * lda + j];
@@ -805,11 +805,15 @@ extern "C" int mgpi_loglikelihood_batch(mgpi_ctx* ctx, const mgpi_mat* X, const 
     mgpi_terms_dev* T = (mgpi_terms_dev*)wptr;  wptr += bytesT;
     double* O = (double*)wptr;             wptr += bytesO;
     int* I = (int*)wptr;
-    MGPI_HIP_TRY(hipMemcpyAsync(T, tb.data(), (size_t)batch * sizeof(mgpi_terms_dev), hipMemcpyHostToDevice, ctx->stream));
-    MGPI_HIP_TRY(hipMemsetAsync(I, 0, (size_t)batch * sizeof(int), ctx->stream));
-    MGPI_TRY(mgpi_launch_cov_batch(ctx, T, d, X->d, X->ld, n, pn, A, lda, strideA, batch));
+    if (batch == 1) {
+        // one problem: the description travels as a kernel argument (no upload) and the specialised build applies
+        MGPI_TRY(mgpi_launch_cov(ctx, tb[0], X->d, X->ld, n, pn, X->d, X->ld, n, pn, 1, 1, 1, A, lda));
+    } else {
+        MGPI_HIP_TRY(hipMemcpyAsync(T, tb.data(), (size_t)batch * sizeof(mgpi_terms_dev), hipMemcpyHostToDevice, ctx->stream));
+        MGPI_TRY(mgpi_launch_cov_batch(ctx, T, d, X->d, X->ld, n, pn, A, lda, strideA, batch));
+    }
     hipLaunchKernelGGL(ll_prepare_kernel, dim3((unsigned)((pn + 255) / 256), IB + 1, (unsigned)batch), dim3(256), 0, ctx->stream, A, lda,
-                       strideA, n, pn, f->d, D0);
+                       strideA, n, pn, f->d, D0, I);
     for (int64_t c0 = 0; c0 < pn; c0 += IB) {
         const int has_prev = c0 > 0;
         const int nfused = (int)(1 + (pn + IB - c0 - IB) / IB);            // the f block is one more row block below
@@ -822,11 +826,12 @@ extern "C" int mgpi_loglikelihood_batch(mgpi_ctx* ctx, const mgpi_mat* X, const 
     }
     hipLaunchKernelGGL(ll_finish_kernel, dim3((unsigned)batch), dim3(256), 0, ctx->stream, A, lda, strideA, n, pn, S, I, O);
     MGPI_HIP_TRY(hipGetLastError());
-    MGPI_HIP_TRY(hipMemcpyAsync(out, O, (size_t)batch * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    std::vector<int> ih((size_t)batch);
-    MGPI_HIP_TRY(hipMemcpyAsync(ih.data(), I, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    // values and status words sit next to each other: one read-back
+    std::vector<char> back(bytesO + (size_t)batch * sizeof(int));
+    MGPI_HIP_TRY(hipMemcpyAsync(back.data(), O, back.size(), hipMemcpyDeviceToHost, ctx->stream));
     MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (info) for (int b = 0; b < batch; ++b) info[b] = ih[b];
+    memcpy(out, back.data(), (size_t)batch * sizeof(double));
+    if (info) memcpy(info, back.data() + bytesO, (size_t)batch * sizeof(int));
     return 0;
 }
 

@@ -91,11 +91,7 @@ static void pool_release(mgpi_ctx* ctx) {
 
 static int pool_alloc(mgpi_ctx* ctx, size_t bytes, double** out, size_t* got) {
     mgpi_pool* pool = ctx->pool;
-    int best = -1;
-    for (int i = 0; i < (int)pool->blocks.size(); ++i) {
-        const size_t b = pool->blocks[i].bytes;
-        if (b >= bytes && b - bytes <= bytes / 8 && (best < 0 || b < pool->blocks[best].bytes)) best = i;
-    }
+    const int best = mgpi_pool_pick(pool->blocks, bytes);
     if (best >= 0) {
         *out = (double*)pool->blocks[best].ptr;
         *got = pool->blocks[best].bytes;

@@ -107,69 +107,7 @@ __device__ __forceinline__ void frag_pair(const double* __restrict__ lds, int t,
     }
 }
 
-// linear lower-triangle tile index -> (i, j), j <= i
-__device__ __forceinline__ void tri_decode(int64_t idx, int& ti, int& tj) {
-    int i = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
-    while ((int64_t)(i + 1) * (i + 2) / 2 <= idx) ++i;
-    while ((int64_t)i * (i + 1) / 2 > idx) --i;
-    ti = i;
-    tj = (int)(idx - (int64_t)i * (i + 1) / 2);
-}
-
-// Tile order for L2 reuse.  The tile list is cut into bands of GEMM_BAND tile rows; inside a band the order is
-// column-major, so 64 consecutive tiles (= what one XCD has in flight: 32 CUs x 2 workgroups) form an 8 x 8 block
-// that shares 8 A slabs and 8 B slabs through that XCD's 4 MiB L2.  With plain row-major order every tile
-// pulled its own B slab from beyond L2 (measured: 54 % L2 hit rate, 2.5x the algorithmic HBM bytes).
-#define GEMM_BAND 8
-template <bool LOWER>
-__device__ __forceinline__ void tile_decode(int64_t idx, int tm, int tn, int& ti, int& tj) {
-    constexpr int S = GEMM_BAND;
-    if (!LOWER) {
-        const int64_t per_band = (int64_t)S * tn;
-        const int band = (int)(idx / per_band);
-        const int within = (int)(idx - band * per_band);
-        const int rows = (tm - band * S < S) ? (tm - band * S) : S;
-        tj = within / rows;
-        ti = band * S + within - tj * rows;
-        return;
-    }
-    // lower triangle: band b holds rows [bS, bS + rows): rows * bS tiles left of the diagonal block (column-major)
-    // plus the rows x rows lower triangle on the diagonal
-    const int64_t full = (int64_t)(tm / S);                       // number of complete bands
-    auto cum = [](int64_t b) { return (int64_t)S * S * b * (b - 1) / 2 + (int64_t)S * (S + 1) / 2 * b; };
-    int64_t band;
-    if (idx >= cum(full)) {
-        band = full;
-    } else {
-        band = (int64_t)((-0.5 * S + sqrt(0.25 * S * S + 2.0 * S * S * (double)idx)) / (double)(S * S));
-        while (band + 1 <= full && cum(band + 1) <= idx) ++band;
-        while (cum(band) > idx) --band;
-    }
-    const int rows = (tm - (int)band * S < S) ? (tm - (int)band * S) : S;
-    const int64_t within = idx - cum(band);
-    const int64_t left = (int64_t)rows * band * S;
-    if (within < left) {
-        tj = (int)(within / rows);
-        ti = (int)(band * S + within - (int64_t)tj * rows);
-    } else {
-        int ii, jj;
-        tri_decode(within - left, ii, jj);
-        ti = (int)(band * S) + ii;
-        tj = (int)(band * S) + jj;
-    }
-}
-
-// block-cyclic "staircase": which tiles of a rank's LOCAL trailing matrix lie on or below the GLOBAL diagonal.
-// Local tile (ti, tj) belongs to global block row p + P*(bi0 + ti/tpb) and block column q + Q*(bj0 + tj/tpb).
-// Only the (almost entirely) live part is enumerated: per band of GEMM_BAND tile rows the columns up to the last one
-// that band's bottom row reaches; prefix[b] = number of enumerated tiles before band b.  (Enumerating the full
-// rectangle and letting dead tiles exit left the XCD that got the top bands idle: 1.9x slower.)
-#define GEMM_STAIR_BANDS 64
-struct gemm_stair {
-    int on, P, p, Q, q, bi0, bj0, tpb;
-    int nbands;
-    int prefix[GEMM_STAIR_BANDS + 1];
-};
+#include "tile_index.h"
 
 // blockIdx.y selects one problem of a strided batch (operand y starts sA / sB / sC doubles after operand y - 1); the
 // single-problem launches pass a 1-deep grid and zero strides
@@ -194,21 +132,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(int64_t k, const doubl
 
     // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD a contiguous
     // run of the tile list so neighbouring tiles (which share A or B slabs) hit the same L2.
-    int64_t bid = blockIdx.x;
-    {
-        const int64_t q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, loc = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
+    const int64_t bid = gemm_xcd_remap(blockIdx.x, ntiles);
     int ti, tj;
     if (!LOWER && st.on) {   // multi-GPU trailing update: tiles strictly above the global diagonal are not touched
-        int band = 0;
-        while (band + 1 < st.nbands && st.prefix[band + 1] <= bid) ++band;
-        const int within = (int)bid - st.prefix[band];
-        const int rows = (tiles_m - band * GEMM_BAND < GEMM_BAND) ? (tiles_m - band * GEMM_BAND) : GEMM_BAND;
-        tj = within / rows;
-        ti = band * GEMM_BAND + within - tj * rows;
-        const int I = st.p + st.P * (st.bi0 + ti / st.tpb), J = st.q + st.Q * (st.bj0 + tj / st.tpb);
-        if (I < J || (I == J && (ti % st.tpb) < (tj % st.tpb))) return;
+        if (!gemm_stair_decode(st, bid, tiles_m, ti, tj)) return;
     } else {
         tile_decode<LOWER>(bid, tiles_m, tiles_n, ti, tj);
     }
@@ -335,21 +262,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_pipe_kernel(int64_t k, const 
     __shared__ __attribute__((aligned(16))) double lds[2 * (GA::doubles + GB::doubles)];
     constexpr int STAGE = GA::doubles + GB::doubles;
 
-    int64_t bid = blockIdx.x;
-    {
-        const int64_t q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, loc = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
+    const int64_t bid = gemm_xcd_remap(blockIdx.x, ntiles);
     int ti, tj;
     if (!LOWER && st.on) {
-        int band = 0;
-        while (band + 1 < st.nbands && st.prefix[band + 1] <= bid) ++band;
-        const int within = (int)bid - st.prefix[band];
-        const int rows = (tiles_m - band * GEMM_BAND < GEMM_BAND) ? (tiles_m - band * GEMM_BAND) : GEMM_BAND;
-        tj = within / rows;
-        ti = band * GEMM_BAND + within - tj * rows;
-        const int I = st.p + st.P * (st.bi0 + ti / st.tpb), J = st.q + st.Q * (st.bj0 + tj / st.tpb);
-        if (I < J || (I == J && (ti % st.tpb) < (tj % st.tpb))) return;
+        if (!gemm_stair_decode(st, bid, tiles_m, ti, tj)) return;
     } else {
         tile_decode<LOWER>(bid, tiles_m, tiles_n, ti, tj);
     }
@@ -721,21 +637,9 @@ extern "C" int mgpi_gemm_nt_stair_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mg
     MGPI_REQUIRE(m % 128 == 0 && n % 128 == 0 && k % GEMM_BK == 0, "mgpi_gemm_nt_stair_dev: extents must be tile multiples");
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
     gemm_stair st = no_stair();
-    st.on = 1; st.P = P; st.p = p; st.Q = Q; st.q = q; st.bi0 = bi0; st.bj0 = bj0; st.tpb = nb / 128;
-    const int tm = (int)(m / 128), tn = (int)(n / 128), tpb = st.tpb;
-    st.nbands = (tm + GEMM_BAND - 1) / GEMM_BAND;
-    MGPI_REQUIRE(st.nbands <= GEMM_STAIR_BANDS, "mgpi_gemm_nt_stair_dev: local trailing matrix has too many tile rows (%d)", tm);
-    int64_t total = 0;
-    for (int b = 0; b < st.nbands; ++b) {
-        st.prefix[b] = (int)total;
-        const int rows = (tm - b * GEMM_BAND < GEMM_BAND) ? (tm - b * GEMM_BAND) : GEMM_BAND;
-        const int last = b * GEMM_BAND + rows - 1;
-        const int64_t gr = (int64_t)(p + P * (bi0 + last / tpb)) * tpb + last % tpb;      // global tile row of the band's bottom row
-        int cmax = 0;                                                                        // columns it reaches
-        while (cmax < tn && (int64_t)(q + Q * (bj0 + cmax / tpb)) * tpb + cmax % tpb <= gr) ++cmax;
-        total += (int64_t)rows * cmax;
-    }
-    st.prefix[st.nbands] = (int)total;
+    const int tm = (int)(m / 128), tn = (int)(n / 128);
+    const int64_t total = gemm_stair_fill(st, tm, tn, P, p, Q, q, bi0, bj0, nb / 128);
+    MGPI_REQUIRE(total >= 0, "mgpi_gemm_nt_stair_dev: local trailing matrix has too many tile rows (%d)", tm);
     if (total == 0) return 0;
     mgpi_prof_begin(ctx, 0);
     int rc = use_pipe() ? launch_pipe<false, false>(ctx, m, n, k, A->d, A->ld, B->d, B->ld, C->d, C->ld, st)

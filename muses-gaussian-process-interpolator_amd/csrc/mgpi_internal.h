@@ -60,7 +60,7 @@ struct mgpi_mat {
     size_t dinv_bytes;
 };
 
-struct mgpi_pool_block { void* ptr; size_t bytes; };
+#include "tile_index.h"
 struct mgpi_pool {
     std::vector<mgpi_pool_block> blocks;   // oldest first
     size_t held = 0, cap = 0;

@@ -221,6 +221,67 @@ class Interpolator(HyperParameterSearch):
         stage.end()
         return out.to_host().reshape(-1)
 
+    #--- the train-once / query-many flows of bin/mgpi-compress:60-82 and bin/mgpi-predict:58-94, x resident (additive)
+
+    def compress_many(self, source_x, source_f, kernel_params, verbose=False):
+        """one compressed vector per row of kernel_params (kernel parameter vectors in kernel order, what
+        bin/mgpi-compress loops over): (P, N).  x and f are uploaded once and the N x N buffer is reused, P kernel-matrix
+        builds + factorisations + solves run back to back.  The kernel is left at the LAST row, like the loop upstream."""
+        ctx = self.context
+        x = _points(source_x)
+        f = _lib.as_f64(source_f).reshape(-1)
+        assert len(f) == len(x), 'source_f has %d entries for %d source points' % (len(f), len(x))
+        rows = np.atleast_2d(np.asarray(kernel_params, dtype=float))
+        n = len(x)
+        X = _lib.DeviceMatrix.from_host(ctx, x)
+        F = _lib.DeviceMatrix.from_host(ctx, f)
+        L = _lib.DeviceMatrix(ctx, n, n, wide=True)
+        a = _lib.DeviceMatrix(ctx, n, 1)
+        out = np.empty((len(rows), n))
+        if verbose:
+            print('generating compressed data for %d parameter sets' % len(rows))
+        for p, row in enumerate(rows):
+            self.kernel.update(*row)
+            if verbose:
+                print('    %s' % self.kernel)
+            desc, count = _lib.make_terms(_flatten(self.kernel, self.nugget))
+            _lib.check(ctx.lib.mgpi_cov_matrix_dev(ctx.handle, X.handle, None, desc, count, 1, L.handle))
+            try:
+                _lib.check(ctx.lib.mgpi_potrf_dev(ctx.handle, L.handle, None))
+            except _lib.NotPositiveDefinite as err:
+                raise np.linalg.LinAlgError('source-source covariance is not positive definite (pivot %d) for parameter set %d'
+                                            % (err.pivot, p))
+            _lib.check(ctx.lib.mgpi_mat_copy(ctx.handle, F.handle, a.handle))
+            _lib.check(ctx.lib.mgpi_potrs_dev(ctx.handle, L.handle, a.handle))
+            out[p] = a.to_host().reshape(-1)
+        return out
+
+    def predict_average(self, target_x, source_x, compressed, kernel_params, verbose=False):
+        """mean over the P (compressed vector, kernel parameter row) pairs of predict(): bin/mgpi-predict's loop
+        (:75-82) with target_x and source_x uploaded once.  The kernel is left at the last row."""
+        ctx = self.context
+        xs = _points(target_x)
+        x = _points(source_x)
+        assert xs.shape[1] == x.shape[1], 'conflicting number of dimensions for x1 and x2'
+        comp = np.atleast_2d(np.asarray(compressed, dtype=float))
+        rows = np.atleast_2d(np.asarray(kernel_params, dtype=float))
+        assert len(comp) == len(rows), '%d compressed datasets for %d parameter sets' % (len(comp), len(rows))
+        assert comp.shape[1] == len(x), 'compressed has %d entries for %d source points' % (comp.shape[1], len(x))
+        XS = _lib.DeviceMatrix.from_host(ctx, xs)
+        X = _lib.DeviceMatrix.from_host(ctx, x)
+        A = _lib.DeviceMatrix(ctx, len(x), 1)
+        out = _lib.DeviceMatrix(ctx, len(xs), 1)
+        mean = 0.0
+        if verbose:
+            print('generating predictions for %d compressed datasets' % len(comp))
+        for alpha, row in zip(comp, rows):
+            self.kernel.update(*row)
+            desc, count = _lib.make_terms(_flatten(self.kernel))
+            A.upload(alpha)
+            _lib.check(ctx.lib.mgpi_predict_mean_dev(ctx.handle, XS.handle, X.handle, desc, count, A.handle, out.handle))
+            mean = mean + out.to_host().reshape(-1)
+        return mean / len(comp)
+
     #--- condition (interpolators.py:136-204)
 
     def condition(self, target_x, source_x, source_f, verbose=False, Verbose=False):

@@ -59,14 +59,14 @@ class LogPosterior(object):
         if not todo:
             return out
         if self._resident is None:
-            self._resident = self.interp.resident(self.source_x, self.source_f)
+            self._resident = self.interp.resident(self.source_x, self.source_f) or ()
         # full kernel parameter vectors: the fixed ones at their values, the free ones from the rows
         names = list(self.interp.kernel._params)
         base = np.array(self.interp.kernel.params, dtype=float)
         cols = [names.index(name) for name in self.free]
         rows = np.tile(base, (len(todo), 1))
         rows[:, cols] = params[todo]
-        logl, pivot = self.interp.loglikelihoods(self.source_x, self.source_f, rows, resident=self._resident, **self.kwargs)
+        logl, pivot = self.interp.loglikelihoods(self.source_x, self.source_f, rows, resident=self._resident or None, **self.kwargs)
         for j, i in enumerate(todo):
             if pivot[j] == 0:          # not positive definite at these parameters: an excluded point
                 out[i] = logl[j] / self.temperature + logp[i]

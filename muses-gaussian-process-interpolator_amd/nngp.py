@@ -196,6 +196,28 @@ class NearestNeighborInterpolator(Interpolator):
         mean, diag = self._2diag(source_x, source_x, source_f, neighbors, verbose=verbose)
         return -0.5 * np.sum((mean - source_f)**2 / diag) - 0.5 * np.sum(np.log(diag)) - 0.5 * len(source_x) * np.log(2 * np.pi)
 
+    def resident(self, source_x, source_f):
+        return None              # the NNGP kernels take host arrays (neighbour sets are host-side index lists, :744, :833)
+
+    def loglikelihoods(self, source_x, source_f, kernel_params, resident=None, neighbors=None, verbose=False):
+        """(values (B,), flags (B,)) for every row of kernel_params - the vectorised form LogPosterior calls; the NNGP
+        likelihood is one search-free launch per row (the neighbour sets do not depend on the kernel parameters), so the
+        rows simply run one after the other.  A row that produces a NaN / non-positive conditional variance (the
+        reference's `safe` asserts, :766-772) gets -inf and flag 1."""
+        rows = np.atleast_2d(np.asarray(kernel_params, dtype=float))
+        keep = np.array(self.kernel.params, dtype=float)
+        out, flags = np.full(len(rows), -np.inf), np.zeros(len(rows), dtype=np.int32)
+        try:
+            for i, row in enumerate(rows):
+                self.kernel.update(*row)
+                try:
+                    out[i] = self.loglikelihood(source_x, source_f, neighbors=neighbors, verbose=verbose)
+                except AssertionError:
+                    flags[i] = 1
+        finally:
+            self.kernel.update(*keep)
+        return out, flags
+
     #--- prediction (interpolators.py:850-884)
 
     def condition_diag(self, target_x, source_x, source_f, verbose=False, Verbose=False):
@@ -231,10 +253,26 @@ class NearestNeighborInterpolator(Interpolator):
 
     sample = rvs
 
+    # compress / predict: upstream's gap is KEPT, on purpose.
+    #
+    # The reference leaves both as NotImplementedError with a sketch (mgpi/interpolators.py:875-938): compress would be
+    # inv(K_nngp) @ f and predict K_nngp(x*, x) @ compressed.  In the NNGP that pair has no content of its own.  With the
+    # samples in rank order the NNGP precision is K_nngp^-1 = (I - A)^T D^-1 (I - A) (A = the per-sample neighbour weights
+    # b_i, D = the conditional variances - exactly what _2diag evaluates sample by sample), and a target outside the
+    # reference set is conditionally independent of everything but its neighbour set N(x*), so its covariance row is
+    # K_nngp(x*, x) = b*^T K_nngp[N(x*), :].  Then
+    #     predict(compress(f)) = b*^T K_nngp[N(x*), :] K_nngp^-1 f = b*^T f[N(x*)]
+    # which is condition()'s mean, term by term: the "compressed" vector would have to be expanded back to f (two sparse
+    # triangular solves) before a single prediction could use it, and the N x N object upstream's sketch inverts is never
+    # sparse on the covariance side.  condition / condition_diag are the prediction entry points of this class; a saved
+    # model is (sorted source_x, source_f, kernel parameters).  The dense Interpolator.compress / predict remain available
+    # through the base class for callers that want the exact process on a subset.
     def compress(self, source_x, source_f, verbose=False, Verbose=False):
-        raise NotImplementedError('the reference leaves NearestNeighborInterpolator.compress unimplemented '
-                                  '(mgpi/interpolators.py:888-899); use condition / condition_diag')
+        raise NotImplementedError('NearestNeighborInterpolator.compress is left unimplemented, as in the reference '
+                                  '(mgpi/interpolators.py:888-899): in the NNGP predict(compress(f)) reduces to '
+                                  "condition()'s mean (see the comment above this method); use condition / condition_diag")
 
     def predict(self, target_x, source_x, compressed, verbose=False, Verbose=False):
-        raise NotImplementedError('the reference leaves NearestNeighborInterpolator.predict unimplemented '
-                                  '(mgpi/interpolators.py:921-926); use condition / condition_diag')
+        raise NotImplementedError('NearestNeighborInterpolator.predict is left unimplemented, as in the reference '
+                                  '(mgpi/interpolators.py:921-926): K_nngp(x*, x) K_nngp^-1 f = b*^T f[N(x*)] is '
+                                  "condition()'s mean; use condition / condition_diag")

@@ -144,3 +144,81 @@ def test_all_three_example_kernels_end_to_end(tmp_path):
         oracle.MATERN_ZERO_LIMIT = False
     assert relmax(mean, want_mean) < mean_tol(cond)
     assert np.max(np.abs(cov - want_cov)) / 0.02 < var_tol(cond)
+
+
+def test_containers_round_trip_with_the_reference_field_names(tmp_path):
+    """save/load_compressed_data and save/load_conditioned_data as `.npz` mirrors of mgpi/io.py:294-387: the reference's
+    field names, shapes and return order; no pickle; the HDF spelling raises ImportError without h5py, like upstream"""
+    rng = np.random.default_rng(0)
+    source_x, params, compressed = rng.random((7, 2)), rng.random((3, 4)), rng.random((3, 7))
+    path = str(tmp_path / 'model.npz')
+    mgpi.save_compressed_data(path, source_x, compressed, params, xcols=['muB_MeV', 'T_MeV'], fcol='speed_of_sound')
+    with np.load(path, allow_pickle=False) as raw:
+        assert sorted(raw.files) == ['compressed', 'fcol', 'params', 'source_x', 'xcols']
+    sx, comp, par, xcols, fcol = mgpi.load_compressed_data(path)
+    assert np.array_equal(sx, source_x) and np.array_equal(comp, compressed) and np.array_equal(par, params)
+    assert xcols == ['muB_MeV', 'T_MeV'] and fcol == 'speed_of_sound'
+    mgpi.save_compressed_data(path, source_x, compressed, params)
+    assert mgpi.load_compressed_data(path)[3:] == (['x0', 'x1'], 'f')                 # io.py:329-330 defaults
+    target_x, mean, cov = rng.random((5, 2)), rng.random(5), rng.random((5, 5))
+    out = str(tmp_path / 'out.npz')
+    mgpi.save_conditioned_data(out, target_x, mean, xcols=['a', 'b'], fcol='y')
+    m, c, tx, xc, fc = mgpi.load_conditioned_data(out)
+    assert c is None and np.array_equal(m, mean) and np.array_equal(tx, target_x) and (xc, fc) == (['a', 'b'], 'y')
+    mgpi.save_conditioned_data(out, target_x, mean, cov=cov)
+    assert np.array_equal(mgpi.load_conditioned_data(out)[1], cov)
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError):
+            mgpi.save_compressed_data(str(tmp_path / 'model.hdf5'), source_x, compressed, params)
+        with pytest.raises(ImportError):
+            mgpi.load_conditioned_data(str(tmp_path / 'out.h5'))
+    np.savetxt(tmp_path / 'targets.csv', rng.random((4, 3)), delimiter=',', header='T_MeV,junk,muB_MeV', comments='')
+    t = mgpi.load_target_data(str(tmp_path / 'targets.csv'), ['muB_MeV', 'T_MeV'])
+    assert t.shape == (4, 2)
+    with pytest.raises(AssertionError):
+        mgpi.load_target_data(str(tmp_path / 'targets.csv'), ['muB_MeV', 'missing'])
+
+
+@pytest.mark.gpu
+def test_compress_then_predict_flows_against_the_oracle(tmp_path):
+    """bin/mgpi-compress:60-82 -> container -> bin/mgpi-predict:58-94 as tools/mgpi_flows.py: P kernel-parameter rows,
+    one compressed vector each (x resident), saved with the reference's field names; predict averages the P means.
+    Every row is checked against the oracle's compress / predict."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from oracle import mgpi_oracle as oracle
+    write_case(tmp_path)
+    rows = np.array([[0.1, 10.0, 20.0], [0.12, 9.0, 25.0], [0.08, 14.0, 18.0]])
+    np.savetxt(tmp_path / 'rows.csv', rows, delimiter=',', header='sigma,length0,length1', comments='')
+    rng = np.random.default_rng(3)
+    targets = np.column_stack([rng.uniform(0, 150, 40), rng.uniform(30, 100, 40)])
+    np.savetxt(tmp_path / 'targets.csv', targets, delimiter=',', header='muB_MeV,T_MeV', comments='')
+    tool = os.path.join(ROOT, 'tools', 'mgpi_flows.py')
+    run = lambda *a: subprocess.run([sys.executable, tool] + list(a), cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    out = run('compress', 'data.ini', 'interp.ini', 'model.npz', '--kernel-params', 'rows.csv', '-v')
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'generating compressed data for 3 parameter sets' in out.stdout
+    source_x, compressed, params, xcols, fcol = mgpi.load_compressed_data(str(tmp_path / 'model.npz'))
+    assert compressed.shape == (3, 512) and np.array_equal(params, rows) and xcols == ['muB_MeV', 'T_MeV'] and fcol == 'speed_of_sound'
+    (sx, sf), _ = mgpi.parse_table(str(tmp_path / 'data.ini'))
+    assert np.array_equal(sx, source_x)
+    nug = [oracle.term_white(1e-4)]
+    means = []
+    for row, alpha in zip(rows, compressed):
+        kern = [oracle.term_se(row[0], row[1], row[2])]
+        ref = oracle.compress(kern, nug, sx, sf)
+        assert relmax(alpha, ref) < 1e-6                      # cond(K) ~ 2.5e7 for this table (conftest.mean_tol applies to means)
+        means.append(oracle.predict(kern, targets, sx, ref))
+    out = run('predict', 'model.npz', 'targets.csv', 'interp.ini', 'pred.npz', '-v')
+    assert out.returncode == 0, out.stderr[-2000:]
+    mean, cov, tx, xc, fc = mgpi.load_conditioned_data(str(tmp_path / 'pred.npz'))
+    assert cov is None and np.array_equal(tx, targets) and (xc, fc) == (xcols, fcol)
+    assert relmax(mean, np.mean(means, axis=0)) < 1e-8
+    out = run('condition', 'data.ini', 'targets.csv', 'interp.ini', 'cond.npz', '--diag')
+    assert out.returncode == 0, out.stderr[-2000:]
+    m2, var, _, _, _ = mgpi.load_conditioned_data(str(tmp_path / 'cond.npz'))
+    rm, rc = oracle.condition([oracle.term_se(0.1, 10.0, 20.0)], nug, targets, sx, sf)
+    assert relmax(m2, rm) < 1e-8 and np.max(np.abs(var - np.diag(rc))) < 1e-8 * 0.01

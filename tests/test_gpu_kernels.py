@@ -238,12 +238,17 @@ def test_trtri_neg_strided_batch(ctx, w, batch, row_step, col_step):
                                  {'MGPI_SUPER_PANELS': '4', 'MGPI_SUPER_MIN': '512'}, {'MGPI_VAR_DINV': '0'}, {'MGPI_PANEL_RIGHT': '0'}, {'MGPI_PANEL_FUSE': '0'},
                                  {'MGPI_PANEL_FUSE_ROWS': '1000000', 'MGPI_SUPER_MIN': '512'},
                                  {'MGPI_TRSM_SUPER': '1', 'MGPI_TRSM_SUPER_MIN': '512'}, {'MGPI_TRSM_SUPER': '2', 'MGPI_TRSM_SUPER_MIN': '512'},
-                                 {'MGPI_TRSM_SUPER': '4', 'MGPI_TRSM_SUPER_MIN': '512'}, {}],
+                                 {'MGPI_TRSM_SUPER': '4', 'MGPI_TRSM_SUPER_MIN': '512'},
+                                 {'MGPI_PANEL_STEP': '0'}, {'MGPI_PANEL_STEP_SPLIT': '0', 'MGPI_PANEL_STEP_ROWS': '512'},
+                                 {'MGPI_PANEL_STEP_ROWS': '0'}, {'MGPI_PANEL_STEP_ROWS': '1000000', 'MGPI_SUPER_MIN': '512'},
+                                 {'MGPI_COV_FAST': '0'}, {'MGPI_PREDICT_MFMA': '1'}, {'MGPI_GEMM_SKINNY_TILES': '0'}, {'MGPI_BCAST': 'rccl'}, {}],
                          ids=lambda e: ','.join('%s=%s' % kv for kv in e.items()) or 'defaults')
 def test_developer_switch_variants(env):
     """every kernel variant kept behind an environment switch (DESIGN.md section c) computes the same results:
     the plain and register-staged 128x128 gemm, the ping-pong gemm, no look-ahead, no buffer pool, /opt/rocm's runtime,
-    1 / 2 / 4 panels per trailing update (with a threshold small enough for the two-level schedule to engage)"""
+    1 / 2 / 4 panels per trailing update (with a threshold small enough for the two-level schedule to engage), the
+    round-1 panel kernels (MGPI_PANEL_STEP=0), the one-launch panel step everywhere / split everywhere / not for large
+    panels, the general kernel-term loop, the MFMA form of predict-mean, 128-wide tiles for skinny updates"""
     import os
     import subprocess
     import sys

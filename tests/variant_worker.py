@@ -47,6 +47,8 @@ K = mgpi.Interpolator._x2cov(x, x, it.kernel + it.nugget)
 alpha = it.compress(x, f)
 assert np.max(np.abs(K @ alpha - f)) < 1e-10 * np.max(np.abs(f))
 mean, var = it.condition_diag(x[:300] + 0.01, x, f)
+Ks300 = mgpi.Interpolator._x2cov(x[:300] + 0.01, x, it.kernel)
+assert np.max(np.abs(mean - Ks300 @ alpha)) < 1e-10 * np.max(np.abs(mean))
 ll = it.loglikelihood(x, f)
 s, logdet = np.linalg.slogdet(K)
 assert abs(ll - (-0.5 * f @ alpha - 0.5 * logdet - 0.5 * n * np.log(2 * np.pi))) < 1e-9 * abs(ll)

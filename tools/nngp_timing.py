@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """developer probe: NearestNeighborInterpolator.loglikelihood wall-clock at the training-set sizes of the reference's
-published NNGP timings (test/uiuc/uiuc-test-nngp-timing.txt: k = 10 neighbours, ordered by coordinate 0, SE(D=2) +
-WhiteNoise sigma/1000; columns "NNGP" = sort + neighbour search + likelihood, "(presorted)NNGP" = likelihood only).
+published NNGP timings (test/uiuc/uiuc-test-nngp-timing.txt, produced with `--num-neighbors 20 --order-by-index 0`
+per test/uiuc/README.md:37-45: k = 20 neighbours, ordered by coordinate 0, SE(D=2) + WhiteNoise sigma/1000; argv[1]
+overrides k; columns "NNGP" = sort + neighbour search + likelihood, "(presorted)NNGP" = likelihood only).
 Synthetic checkerboard-thinned (muB, T) grid of the same sizes; host arrays in, scalar out."""
 import os
 import sys
@@ -19,12 +20,14 @@ PUBLISHED = {16: (0.0031, 0.0027), 338: (0.12, 0.08), 1311: (0.55, 0.40), 5160: 
 
 
 def main():
+    k = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    print('num_neighbors = %d, order_by_index = 0' % k, flush=True)
     for n, pub in PUBLISHED.items():
         x, f, ell = table(n)
         f = f - f.mean()
         sig = 1.5 * np.std(f)
         kern = mgpi.CombinedKernel(mgpi.SquaredExponentialKernel(sig, *ell), mgpi.WhiteNoiseKernel(sig / 1000))
-        nn = mgpi.NearestNeighborInterpolator(kern, num_neighbors=10, order_by_index=0)
+        nn = mgpi.NearestNeighborInterpolator(kern, num_neighbors=k, order_by_index=0)
         nn.loglikelihood(x, f)
         full, pre, search = [], [], []
         for _ in range(3):
