@@ -172,6 +172,11 @@ __global__ __launch_bounds__(256) void potf2_trsm_kernel(double* __restrict__ A,
 //   * workgroups >= nfused ("update role"): one 64 x 64 tile each of the REST of the panel (column blocks right of this
 //     step's), to which they apply X' - the part of the deferred gemm that is not on this step's critical path.
 // The chain per step is then one launch of (two contraction-64 products + 64 x 64 Cholesky + 64-row substitution).
+// launch_bounds(256, 2): with room for only one workgroup per CU the compiler parks the MFMA accumulators in AGPRs, where
+// v_mfma_f64 issues at less than half the rate (DESIGN.md section c).
+// Measured and dropped: folding the PREVIOUS panel's trailing update (contraction 512) into the column role, to take the
+// skinny column-update gemm off the chain - with operands streamed straight from L2 the 64 x 64 x 512 products per
+// workgroup made a step 2x slower (N = 8192: potrf 13.8 ms against 7.5).
 // `mode` splits the work for LARGE panels, where hundreds of workgroups repeating the 64 x 64 factorisation would take CU
 // time from the trailing update that runs beside the panel:
 //   mode 0  everything in one launch (every column-role workgroup factors the diagonal block itself)
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(256) void potf2_trsm_kernel(double* __restrict__ A,
 //   mode 2  the rest: column-role workgroups for the row blocks BELOW the diagonal block read the images from F
 //           instead of factoring, plus the update-role workgroups
 #define PANEL_F_DOUBLES (IB * IB + IB)
-__global__ __launch_bounds__(256) void panel_step_kernel(double* __restrict__ A, int64_t lda, int64_t c0, int has_prev, int nfused,
+__global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__ A, int64_t lda, int64_t c0, int has_prev, int nfused,
                                                          int rest_cols, int64_t pivot_base, const double* __restrict__ diag0,
                                                          int* __restrict__ info, double* __restrict__ S, double ptol, int mode,
                                                          double* __restrict__ F, int64_t strideA, int64_t strideS, int64_t strideD) {

@@ -296,11 +296,18 @@ struct potf2_acc_rounds {
     static __device__ __forceinline__ void run(panel_double4_t (&acc)[4], panel_lds& s, int w, int g, int c, int& bad,
                                                double* __restrict__ S) {
         constexpr int QK = K / 16, KL = K % 16, B = (K / 4) & 1;
+#ifdef PANEL_STAMPS
+        long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
+        if (K == 32) st0 = clock64();
+#endif
         if (w >= QK && c >= KL && c < KL + 4) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) s.raw[B][16 * w + g + 4 * r][c - KL] = acc[QK][r];
         }
         __syncthreads();
+#ifdef PANEL_STAMPS
+        if (K == 32) st1 = clock64();
+#endif
         const double p00 = s.raw[B][K][0], p10 = s.raw[B][K + 1][0], p20 = s.raw[B][K + 2][0], p30 = s.raw[B][K + 3][0];
         const double p11 = s.raw[B][K + 1][1], p21 = s.raw[B][K + 2][1], p31 = s.raw[B][K + 3][1];
         const double p22 = s.raw[B][K + 2][2], p32 = s.raw[B][K + 3][2], p33 = s.raw[B][K + 3][3];
@@ -322,6 +329,9 @@ struct potf2_acc_rounds {
         const double m32 = q32 * rd2;
         const double d3 = fma(-m32, q32, fma(-m31, q31, fma(-m30, p30, p33))), rd3 = rcp_refined(d3);
         const bool ok3 = d3 > s.dtol[K + 3];
+#ifdef PANEL_STAMPS
+        if (K == 32) { asm volatile("" :: "v"(rd3)); st2 = clock64(); }
+#endif
         if (bad == 0) bad = !ok0 ? K + 1 : (!ok1 ? K + 2 : (!ok2 ? K + 3 : (!ok3 ? K + 4 : 0)));
 #ifdef PANEL_DEBUG
         if (K == 40 && threadIdx.x == 0) {
@@ -343,6 +353,10 @@ struct potf2_acc_rounds {
             return (rw >= K + g) ? wg : 0.0;                         // rows above column K + g's diagonal: nothing
         };
         const double wa = solve(ar, row);
+#ifdef PANEL_STAMPS
+        long long st2a = 0, st2b = 0;
+        if (K == 32) { asm volatile("" :: "v"(wa)); st2a = clock64(); }
+#endif
         if (w >= QK) {
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
@@ -358,11 +372,22 @@ struct potf2_acc_rounds {
                 }
             }
         }
+#ifdef PANEL_STAMPS
+        if (K == 32) { asm volatile("" :: "v"(acc[2][0]), "v"(acc[3][0])); st2b = clock64(); }
+#endif
         // finished entries of columns K..K+3 (zeros above the diagonal, also for the waves above the block)
         const double x = (w >= QK) ? wa * ig : 0.0;
         if (w >= QK) s.Lt[K + g][row] = x;
         if (row == K + g) s.invd[K + g] = ig;
         if (S != nullptr) S[(int64_t)row * IB + K + g] = x;
+#ifdef PANEL_STAMPS
+        if (K == 32) {
+            asm volatile("" :: "v"(acc[2][0]), "v"(acc[3][0]));
+            st3 = clock64();
+            if (threadIdx.x == 192) { panel_stamps[0] = st1 - st0; panel_stamps[1] = st2 - st1; panel_stamps[2] = st3 - st2;
+                                      panel_stamps[3] = st2a - st2; panel_stamps[4] = st2b - st2a; panel_stamps[5] = st3 - st2b; }
+        }
+#endif
         if constexpr (K + 4 < IB) potf2_acc_rounds<K + 4>::run(acc, s, w, g, c, bad, S);
     }
 };

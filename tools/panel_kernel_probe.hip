@@ -2,6 +2,8 @@
 // accumulator-layout panel primitives (one workgroup, stand-alone).
 // build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include -I muses-gaussian-process-interpolator_amd/csrc tools/panel_kernel_probe.hip -o tools/panel_kernel_probe
 #define PANEL_DEBUG 1
+#define PANEL_STAMPS 1
+__device__ long long panel_stamps[8];
 __device__ double panel_debug[16];
 __device__ double panel_debug2[256 * 8];
 #include "panel_device.h"
@@ -10,7 +12,7 @@ __device__ double panel_debug2[256 * 8];
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
-__global__ __launch_bounds__(256) void probe_kernel(double* __restrict__ A, int64_t lda, const double* __restrict__ diag0,
+__global__ __launch_bounds__(256, 2) void probe_kernel(double* __restrict__ A, int64_t lda, const double* __restrict__ diag0,
                                                     double* __restrict__ X, double* __restrict__ S, long long* __restrict__ stamps, int mode, double* __restrict__ dump) {
     __shared__ panel_lds s;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
@@ -143,6 +145,8 @@ int main() {
             if (mode & 1) for (int k = 0; k < n; ++k) { einv = fmax(einv, fabs(dump[n * n + k] - 1.0 / L[k * n + k]));
                 for (int m = k; m < n; ++m) eLt = fmax(eLt, fabs(dump[k * n + m] - L[m * n + k])); }
             printf("   per-wave bad %lld %lld %lld %lld | Lt err %.2e invd err %.2e dtol[42] %.3e\n", st[4], st[5], st[6], st[7], eLt, einv, dump[n * n + n + 42]);
+            long long ps[8]; CK(hipMemcpyFromSymbol(ps, HIP_SYMBOL(panel_stamps), sizeof(ps)));
+            printf("   round 32 (wave 3): write+barrier %lld, reads+pivot chain %lld, solves+mfma+stores %lld cycles (own-row solve %lld, B solves + mfma %lld, rsq + stores %lld)\n", ps[0], ps[1], ps[2], ps[3], ps[4], ps[5]);
             double dbg[16]; CK(hipMemcpyFromSymbol(dbg, HIP_SYMBOL(panel_debug), sizeof(dbg)));
             printf("   dbg: e = %.4e %.4e %.4e %.4e | tol %.3e %.3e %.3e %.3e | ok %g %g %g %g bad %g\n", dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7], dbg[8], dbg[9], dbg[10], dbg[11], dbg[12]);
             double eL = 0, eX = 0, upper = 0;
