@@ -2,6 +2,7 @@
 // row-paired Kernel.cov (mgpi/kernels.py:89-93).  The reference materialises the n1*n2 row pairs; here each
 // workgroup owns one 64x64 output tile, stages the two coordinate slabs in LDS as SoA and never forms pairs.
 #include "cov_device.h"
+#include <stdlib.h>
 
 #define COV_T 64   // output tile edge
 
@@ -17,8 +18,16 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(mgpi_terms_dev t, const d
     __shared__ double s1[DD][COV_T];
     __shared__ __attribute__((aligned(16))) double s2[DD][COV_T];
     const int nd = (D > 0) ? D : t.d;
-    const int64_t row0 = (int64_t)blockIdx.y * COV_T, col0 = (int64_t)blockIdx.x * COV_T;
-    if (lower_only && col0 > row0) return;   // strictly-upper tile: potrf never reads it
+    int64_t row0, col0;
+    if (lower_only) {   // 1-D grid over the tiles on/below the diagonal only (potrf never reads the others): at N = 32768 the
+        int ti, tj;     // full grid launched 131 k workgroups just to have them exit
+        tri_decode(blockIdx.x, ti, tj);
+        row0 = (int64_t)ti * COV_T;
+        col0 = (int64_t)tj * COV_T;
+    } else {
+        row0 = (int64_t)blockIdx.y * COV_T;
+        col0 = (int64_t)blockIdx.x * COV_T;
+    }
 
     const int tid = threadIdx.x;
     for (int idx = tid; idx < COV_T * nd; idx += 256) {
@@ -56,6 +65,104 @@ __global__ __launch_bounds__(256) void cov_tile_kernel(mgpi_terms_dev t, const d
             if (i >= n1 || j + 1 >= n2) v.y = (pad_identity && i == j + 1) ? 1.0 : 0.0;
             *reinterpret_cast<double2*>(&out[i * ldo + j]) = v;
         }
+    }
+}
+
+// The large-D form of the kernel-matrix build (north_star: "wavefront shuffles for the D-reduction"), default for D > 8.  Four lanes (a
+// DPP quad) share one output row of the tile and split the DIMENSIONS: lane q accumulates sum_{k = q mod 4} (dx_k / l_k)^2
+// for FOUR neighbouring columns, a 4 x 4 transpose-reduction inside the quad (three 64-bit DPP exchanges) leaves lane q
+// with the complete sum of column q, and every lane then evaluates exp for its own entry - no redundant exp, the same
+// number of vector instructions per entry as the register loop plus ~9 for the exchange.  What it buys is registers: the
+// general-D register kernel holds 2 x 4 x 16 coordinates per thread (256 VGPRs), this one 4 + 16.  Single
+// SquaredExponential (+ WhiteNoise) kernels only; the summation order differs from the left-to-right loop, which for
+// D >= 8 differs from numpy's 8-way pairwise order anyway.  Measured (N = 8192, SE + WhiteNoise, full matrix): D = 16
+// 0.48 ms against 4.58 ms for the register loop, D = 8 0.31 against 2.26; D = 3 0.23 against 0.12 (tools/cov_shuffle_probe.py).
+template <int XOR>
+__device__ __forceinline__ double cov_quad_xor(double v) {
+    constexpr int ctrl = (XOR == 1) ? 0xB1 /* quad_perm [1,0,3,2] */ : 0x4E /* quad_perm [2,3,0,1] */;
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(256) void cov_tile_shuffle_kernel(mgpi_terms_dev t, const double* __restrict__ x1, int64_t ldx1,
+                                                               int64_t n1, const double* __restrict__ x2, int64_t ldx2,
+                                                               int64_t n2, int lower_only, int pad_identity,
+                                                               double* __restrict__ out, int64_t ldo) {
+    __shared__ double s1[MGPI_MAX_D][COV_T];
+    __shared__ double s2[MGPI_MAX_D][COV_T];
+    const int nd = t.d;
+    int64_t row0, col0;
+    if (lower_only) {
+        int ti, tj;
+        tri_decode(blockIdx.x, ti, tj);
+        row0 = (int64_t)ti * COV_T;
+        col0 = (int64_t)tj * COV_T;
+    } else {
+        row0 = (int64_t)blockIdx.y * COV_T;
+        col0 = (int64_t)blockIdx.x * COV_T;
+    }
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < COV_T * nd; idx += 256) {
+        const int r = idx / nd, k = idx - r * nd;
+        s1[k][r] = (row0 + r < n1) ? x1[(row0 + r) * ldx1 + k] : 0.0;
+        s2[k][r] = (col0 + r < n2) ? x2[(col0 + r) * ldx2 + k] : 0.0;
+    }
+    __syncthreads();
+    const int q = tid & 3, row = tid >> 2;                       // lane part, tile row
+    double a[4], l2[4], il2[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = q + 4 * u;
+        a[u] = (k < nd) ? s1[k][row] : 0.0;
+        l2[u] = (k < nd) ? t.l2[0][k] : 1.0;
+        il2[u] = (k < nd) ? t.inv_l2[0][k] : 1.0;
+    }
+    const bool white = t.nterms == 2;
+    const int64_t i = row0 + row;
+    for (int cg = 0; cg < COV_T; cg += 4) {
+        double p[4];
+        bool same[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            double r = 0.0;
+            bool sm = true;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = q + 4 * u;
+                if (k < nd) {
+                    const double b = s2[k][cg + cc];
+                    const double df = a[u] - b;
+                    sm = sm && (a[u] == b);
+                    r = __dadd_rn(r, mgpi_div_rn(__dmul_rn(df, df), l2[u], il2[u]));
+                }
+            }
+            p[cc] = r;
+            same[cc] = sm;
+        }
+        // 4 x 4 transpose-reduction: after the xor-1 exchange lane q holds the two columns with the parity of q, after
+        // the xor-2 exchange its own column
+        // (every exchange is executed by all four lanes, outside any lane-dependent branch: a DPP read from a lane that
+        // sits out a divergent branch returns 0)
+        const double x0 = cov_quad_xor<1>(p[0]), x1 = cov_quad_xor<1>(p[1]), x2 = cov_quad_xor<1>(p[2]), x3 = cov_quad_xor<1>(p[3]);
+        const double e0 = (q & 1) ? p[1] + x1 : p[0] + x0;        // column (q & 1), lanes q and q ^ 1
+        const double e1 = (q & 1) ? p[3] + x3 : p[2] + x2;        // column 2 + (q & 1)
+        const double y0 = cov_quad_xor<2>(e0), y1 = cov_quad_xor<2>(e1);
+        const double f = (q & 2) ? e1 + y1 : e0 + y0;             // column q, all four lanes
+        double val = __dmul_rn(t.sig2[0], mgpi_exp_neg(f));
+        if (white) {
+            // all dimensions equal <=> every part found its share equal: reduce the flags the same way
+            const int f0 = same[0], f1 = same[1], f2 = same[2], f3 = same[3];
+            const int g0 = __builtin_amdgcn_mov_dpp(f0, 0xB1, 0xf, 0xf, true), g1 = __builtin_amdgcn_mov_dpp(f1, 0xB1, 0xf, 0xf, true);
+            const int g2 = __builtin_amdgcn_mov_dpp(f2, 0xB1, 0xf, 0xf, true), g3 = __builtin_amdgcn_mov_dpp(f3, 0xB1, 0xf, 0xf, true);
+            const int s0 = (q & 1) ? (f1 & g1) : (f0 & g0), s1_ = (q & 1) ? (f3 & g3) : (f2 & g2);
+            const int h0 = __builtin_amdgcn_mov_dpp(s0, 0x4E, 0xf, 0xf, true), h1 = __builtin_amdgcn_mov_dpp(s1_, 0x4E, 0xf, 0xf, true);
+            const int all = (q & 2) ? (s1_ & h1) : (s0 & h0);
+            val = __dadd_rn(val, all ? t.sig2[1] : 0.0);
+        }
+        const int64_t j = col0 + cg + q;
+        if (i >= n1 || j >= n2) val = (pad_identity && i == j) ? 1.0 : 0.0;
+        out[i * ldo + j] = val;
     }
 }
 
@@ -153,6 +260,22 @@ int mgpi_launch_cov(mgpi_ctx* ctx, const mgpi_terms_dev& t, const double* x1, in
                  (long long)p1, (long long)p2, COV_T);
     MGPI_REQUIRE(p1 / COV_T <= 65535, "cov: too many row tiles");
     dim3 grid((unsigned)(p2 / COV_T), (unsigned)(p1 / COV_T)), block(256);
+    if (lower_only) {
+        MGPI_REQUIRE(p1 == p2, "cov(lower): the matrix must be square");
+        const int64_t tm = p1 / COV_T;
+        grid = dim3((unsigned)(tm * (tm + 1) / 2), 1);
+    }
+    // the quad-shuffle kernel is the default beyond D = 8, where there is no register kernel with a compile-time D (the
+    // run-time-D register loop holds 2 x 4 x 16 coordinates per thread); up to 8 dimensions the register kernels are
+    // faster (D = 8: 0.21 ms against 0.31 at N = 8192) and sum in the reference's own order.  MGPI_COV_SHUFFLE=1 forces it for every D, =0 switches it off.
+    static const int shuffle_env = getenv("MGPI_COV_SHUFFLE") ? atoi(getenv("MGPI_COV_SHUFFLE")) : -1;
+    const bool shuffle_variant = shuffle_env == 1 || (shuffle_env != 0 && t.d > 8);
+    if (shuffle_variant && t.fast_mix >= 1) {
+        hipLaunchKernelGGL(cov_tile_shuffle_kernel, grid, block, 0, ctx->stream, t, x1, ldx1, n1, x2, ldx2, n2, lower_only, pad_identity,
+                           out, ldo);
+        MGPI_HIP_TRY(hipGetLastError());
+        return 0;
+    }
 #define MGPI_COV_LAUNCH(DV, MV)                                                                                   \
     hipLaunchKernelGGL((cov_tile_kernel<DV, MV>), grid, block, 0, ctx->stream, t, x1, ldx1, n1, x2, ldx2, n2,     \
                        lower_only, pad_identity, out, ldo)
@@ -167,9 +290,14 @@ int mgpi_launch_cov(mgpi_ctx* ctx, const mgpi_terms_dev& t, const double* x1, in
         MGPI_COV_CASE(2)
         MGPI_COV_CASE(3)
         MGPI_COV_CASE(4)
-        case 5: MGPI_COV_LAUNCH(5, 0); break;
-        case 6: MGPI_COV_LAUNCH(6, 0); break;
-        default: MGPI_COV_LAUNCH(0, 0);
+        MGPI_COV_CASE(5)
+        MGPI_COV_CASE(6)
+        MGPI_COV_CASE(7)
+        MGPI_COV_CASE(8)
+        default:
+            if (t.fast_mix == 1) MGPI_COV_LAUNCH(0, 1);
+            else if (t.fast_mix == 2) MGPI_COV_LAUNCH(0, 2);
+            else MGPI_COV_LAUNCH(0, 0);
     }
 #undef MGPI_COV_LAUNCH
 #undef MGPI_COV_CASE

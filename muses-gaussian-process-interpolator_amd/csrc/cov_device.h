@@ -124,13 +124,16 @@ __device__ __forceinline__ double mgpi_exp_neg(double r) {
 template <int D, int MIX>
 __device__ __forceinline__ double mgpi_cov_entry_fast(const mgpi_terms_dev& t, const double* __restrict__ a,
                                                       const double* __restrict__ b) {
+    const int nd = (D > 0) ? D : t.d;                              // D == 0: run-time dimensionality, still no term loop
     double r = 0.0;
     bool same = true;
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
-        const double df = a[k] - b[k];
-        same = same && (a[k] == b[k]);
-        r = __dadd_rn(r, mgpi_div_rn(__dmul_rn(df, df), t.l2[0][k], t.inv_l2[0][k]));
+    for (int k = 0; k < ((D > 0) ? D : MGPI_MAX_D); ++k) {
+        if (k < nd) {
+            const double df = a[k] - b[k];
+            same = same && (a[k] == b[k]);
+            r = __dadd_rn(r, mgpi_div_rn(__dmul_rn(df, df), t.l2[0][k], t.inv_l2[0][k]));
+        }
     }
     double val = __dmul_rn(t.sig2[0], mgpi_exp_neg(r));
     if (MIX == 2) val = __dadd_rn(val, same ? t.sig2[1] : 0.0);
@@ -186,10 +189,10 @@ __device__ __forceinline__ double mgpi_cov_entry_range(const mgpi_terms_dev& t, 
     return val;
 }
 
-// MIX is a compile-time copy of t.fast_mix (the launchers switch on it); D == 0 always takes the general loop
+// MIX is a compile-time copy of t.fast_mix (the launchers switch on it)
 template <int D, int MIX = 0>
 __device__ __forceinline__ double mgpi_cov_entry(const mgpi_terms_dev& t, const double* __restrict__ a,
                                                  const double* __restrict__ b) {
-    if constexpr (D > 0 && MIX > 0) return mgpi_cov_entry_fast<D, MIX>(t, a, b);
+    if constexpr (MIX > 0) return mgpi_cov_entry_fast<D, MIX>(t, a, b);
     else return mgpi_cov_entry_range<D>(t, a, b, 0, t.nterms);
 }

@@ -155,7 +155,14 @@ extern "C" int mgpi_predict_mean_dev(mgpi_ctx* ctx, const mgpi_mat* Xs, const mg
         MGPI_PM_CASE(2)
         MGPI_PM_CASE(3)
         MGPI_PM_CASE(4)
-        default: MGPI_PM_LAUNCH(0, 0);
+        MGPI_PM_CASE(5)
+        MGPI_PM_CASE(6)
+        MGPI_PM_CASE(7)
+        MGPI_PM_CASE(8)
+        default:            // more than 8 dimensions: run-time loop over the dimensions, still without the term loop
+            if (t.fast_mix == 1) MGPI_PM_LAUNCH(0, 1);
+            else if (t.fast_mix == 2) MGPI_PM_LAUNCH(0, 2);
+            else MGPI_PM_LAUNCH(0, 0);
     }
 #undef MGPI_PM_LAUNCH
 #undef MGPI_PM_CASE
