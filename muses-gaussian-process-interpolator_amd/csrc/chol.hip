@@ -841,7 +841,12 @@ extern "C" int mgpi_loglikelihood_batch(mgpi_ctx* ctx, const mgpi_mat* X, const 
 }
 
 // ---- multi-rhs triangular solves:  L X = B (trans = 0),  L^T X = B (trans = 1),  B is (n x m) wide ------
-static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ldb, int64_t ncols, int trans, int use_inv = 0) {
+// Xout (forward solve with the inverse diagonal blocks only): the SOLVED blocks are written there instead of over B - rows
+// of B are dead once their block is solved, so nothing is copied back, and the product with the inverse block starts from
+// zero accumulators instead of a cleared scratch tile (C5: a memset and a copy of 512 x 37 k doubles per block, 14 % of the
+// variance time, gone).  B and Xout must not overlap.
+static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ldb, int64_t ncols, int trans, int use_inv = 0,
+                        double* Xout = nullptr) {
     const int64_t pn = Lm->prows <= Lm->pcols ? Lm->prows : mgpi_roundup(Lm->rows, IB);
     const int64_t lda = Lm->ld, nb = ctx->nb;
     const double* L = Lm->d;
@@ -850,29 +855,32 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
         // the variance path may replace the chain of a diagonal block solve by one gemm with the block's inverse
         double* T = nullptr;
         size_t tbytes = 0;
-        if (use_inv && pn > nb) {
-            MGPI_TRY(ensure_dinv(ctx, Lm));
-            MGPI_TRY(mgpi_pool_alloc(ctx, (size_t)nb * (size_t)nc * sizeof(double), &T, &tbytes));
-        }
+        const bool inv = use_inv && pn > nb;
+        if (inv) MGPI_TRY(ensure_dinv(ctx, Lm));
+        if (inv && Xout == nullptr) MGPI_TRY(mgpi_pool_alloc(ctx, (size_t)nb * (size_t)nc * sizeof(double), &T, &tbytes));
         struct scratch_guard {      // T goes back to the pool on every way out (reuse is ordered on the main stream, which
             mgpi_ctx* c;            // has joined the second one by then - or the call failed and nothing runs on T any more)
             double*& p;
             size_t& b;
             ~scratch_guard() { if (p) mgpi_pool_free(c, p, b); }
         } release_T{ctx, T, tbytes};
+        // where later updates read the solved rows of a block from
+        const double* X = (inv && Xout != nullptr) ? Xout : B;
         // rows [r0, r0+w) of B <- L_bb^-1 (rows of B): 64-wide inner blocks, left-looking inside the outer block
         auto solve_diag_block = [&](int64_t r0, int64_t w) -> int {
-            if (T != nullptr) {
-                // T = 0 - (-(L_bb)^-1) B_b, then back over B_b; full-size tiles whatever the stream
+            if (inv) {
+                // X_b = 0 - (-(L_bb)^-1) B_b; full-size tiles whatever the stream
                 const int lean = ctx->lean;
                 ctx->lean = 0;
-                hipError_t e = hipMemsetAsync(T, 0, (size_t)w * (size_t)nc * sizeof(double), ctx->stream);
-                int rc = (e == hipSuccess) ? mgpi_launch_gemm(ctx, 0, 1, 0, w, nc, w, Lm->dinv + r0 * nb, nb, B + r0 * ldb, ldb, T, nc)
-                                           : MGPI_ERR_HIP;
+                ctx->gemm_zero_c = 1;
+                double* dst = Xout ? Xout + r0 * ldb : T;
+                int rc = mgpi_launch_gemm(ctx, 0, 1, 0, w, nc, w, Lm->dinv + r0 * nb, nb, B + r0 * ldb, ldb, dst, Xout ? ldb : nc);
+                ctx->gemm_zero_c = 0;
                 ctx->lean = lean;
                 if (rc) return rc;
-                hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((nc / 2 + 255) / 256), (unsigned)w), dim3(256), 0, ctx->stream,
-                                   T, nc, B + r0 * ldb, ldb, w, nc);
+                if (!Xout)
+                    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((nc / 2 + 255) / 256), (unsigned)w), dim3(256), 0, ctx->stream,
+                                       T, nc, B + r0 * ldb, ldb, w, nc);
                 return 0;
             }
             for (int64_t c0 = r0; c0 < r0 + w; c0 += IB) {
@@ -895,7 +903,7 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
         static const int64_t super_min = getenv("MGPI_TRSM_SUPER_MIN") ? atoll(getenv("MGPI_TRSM_SUPER_MIN")) : 8192;
         auto super_width = [&](int64_t r0) -> int64_t {
             const int64_t left = pn - r0;
-            int64_t wc = (T != nullptr && r0 > 0 && left - super_blocks * nb >= super_min) ? super_blocks * nb : nb;
+            int64_t wc = (inv && r0 > 0 && left - super_blocks * nb >= super_min) ? super_blocks * nb : nb;
             return wc < left ? wc : left;
         };
         // rows [r0, r0 + wc) of B <- (L restricted to that diagonal super-block)^-1 B: block by block, right-looking
@@ -908,7 +916,7 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
                 if (rc) return rc;
                 const int64_t p1 = p0 + w, rem = r0 + wc - p1;
                 if (rem > 0)    // B[p1:r0+wc,:] -= L[p1:r0+wc, p0:p1] * B[p0:p1,:]
-                    MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, rem, nc, w, L + p1 * lda + p0, lda, B + p0 * ldb, ldb, B + p1 * ldb, ldb));
+                    MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, rem, nc, w, L + p1 * lda + p0, lda, X + p0 * ldb, ldb, B + p1 * ldb, ldb));
             }
             return 0;
         };
@@ -930,7 +938,7 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
                 // second stream: B[r1:r1+w1,:] -= L[r1:r1+w1, r0:r0+w] * B[r0:r0+w,:], then solve that (super-)block
                 MGPI_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_upd, 0));                        // update k-1 of these rows done
                 ctx->stream = ctx->stream2;
-                int rc = mgpi_launch_gemm(ctx, 0, 1, 0, w1, nc, w, L + r1 * lda + r0, lda, B + r0 * ldb, ldb, B + r1 * ldb, ldb);
+                int rc = mgpi_launch_gemm(ctx, 0, 1, 0, w1, nc, w, L + r1 * lda + r0, lda, X + r0 * ldb, ldb, B + r1 * ldb, ldb);
                 if (rc == 0) rc = solve_super(r1, w1, true);
                 ctx->stream = main_stream;
                 MGPI_TRY(rc);
@@ -939,17 +947,17 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
                 // main stream: the remaining rows  B[r1+w1:,:] -= L[r1+w1:, r0:r0+w] * B[r0:r0+w,:]
                 if (t2 > 0) {
                     mgpi_prof_begin(ctx, 4);
-                    MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, t2, nc, w, L + (r1 + w1) * lda + r0, lda, B + r0 * ldb, ldb,
+                    MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, t2, nc, w, L + (r1 + w1) * lda + r0, lda, X + r0 * ldb, ldb,
                                               B + (r1 + w1) * ldb, ldb));
                     mgpi_prof_end(ctx, 4);
                     mgpi_prof_flops(ctx, 4, 2.0 * (double)t2 * (double)nc * (double)w);
                 }
                 MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
             } else {
-                MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, w1, nc, w, L + r1 * lda + r0, lda, B + r0 * ldb, ldb, B + r1 * ldb, ldb));
+                MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, w1, nc, w, L + r1 * lda + r0, lda, X + r0 * ldb, ldb, B + r1 * ldb, ldb));
                 MGPI_TRY(solve_super(r1, w1, false));
                 if (t2 > 0)
-                    MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, t2, nc, w, L + (r1 + w1) * lda + r0, lda, B + r0 * ldb, ldb,
+                    MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, t2, nc, w, L + (r1 + w1) * lda + r0, lda, X + r0 * ldb, ldb,
                                               B + (r1 + w1) * ldb, ldb));
             }
             r0 = r1;
@@ -975,9 +983,16 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
     return 0;
 }
 
-int mgpi_trsm_raw(mgpi_ctx* ctx, const mgpi_mat* L, double* B, int64_t ldb, int64_t ncols, int trans, int use_inv) {
-    static const int allow = getenv("MGPI_VAR_DINV") ? atoi(getenv("MGPI_VAR_DINV")) : 1;     // developer switch
-    return trsm_blocked(ctx, L, B, ldb, ncols, trans, use_inv && allow);
+// Xout != nullptr: the solution is delivered there IF the inverse diagonal blocks are in use (returns 1 in *in_xout), else in
+// place in B as always
+int mgpi_trsm_raw(mgpi_ctx* ctx, const mgpi_mat* L, double* B, int64_t ldb, int64_t ncols, int trans, int use_inv, double* Xout,
+                  int* in_xout) {
+    static const int allow = getenv("MGPI_VAR_DINV") ? atoi(getenv("MGPI_VAR_DINV")) : 1;     // developer switches
+    static const int split = getenv("MGPI_VAR_SPLIT") ? atoi(getenv("MGPI_VAR_SPLIT")) : 1;
+    const int64_t pn = L->prows <= L->pcols ? L->prows : mgpi_roundup(L->rows, IB);
+    const bool to_x = use_inv && allow && split && Xout != nullptr && !trans && pn > ctx->nb;
+    if (in_xout) *in_xout = to_x ? 1 : 0;
+    return trsm_blocked(ctx, L, B, ldb, ncols, trans, use_inv && allow, to_x ? Xout : nullptr);
 }
 
 extern "C" int mgpi_trsm_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* B, int trans) {

@@ -30,6 +30,7 @@ struct mgpi_ctx {
     hipEvent_t ev_join;           // mgpi_ctx_wait: "everything queued on this ctx so far"
     hipEvent_t ev_upd, ev_panel;  // main-stream update of a step done / look-ahead stream's panel (block) done
     int no_lookahead;             // MGPI_NO_LOOKAHEAD=1 (developer switch)
+    int gemm_zero_c;              // the next gemm launches compute C = -A B (accumulators start from 0, C is not read)
     int lean;                     // launch gemms as 64x64 tiles (32 KB LDS, < 104 VGPRs): they can then start next to
                                   // two resident trailing-update workgroups during the look-ahead
     hipEvent_t ev0, ev1;          // tic/toc

@@ -5,7 +5,8 @@
 #include "cov_device.h"
 #include <stdlib.h>
 
-int mgpi_trsm_raw(mgpi_ctx* ctx, const mgpi_mat* L, double* B, int64_t ldb, int64_t ncols, int trans, int use_inv);
+int mgpi_trsm_raw(mgpi_ctx* ctx, const mgpi_mat* L, double* B, int64_t ldb, int64_t ncols, int trans, int use_inv, double* Xout,
+                  int* in_xout);
 
 #define PM_CHUNK 512   // sources staged per workgroup pass
 
@@ -258,7 +259,7 @@ extern "C" int mgpi_predict_var_dev(mgpi_ctx* ctx, const mgpi_mat* Xs, const mgp
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
     const int64_t m = Xs->rows, n = X->rows, pn = L->prows;
     if (m_slab <= 0) {
-        // default: a V slab of ~4 GB (288 GB of HBM: wide slabs mean fewer, larger update gemms - at N = 13160 a slab of
+        // default: two V slabs (work rows, solved rows) of ~4 GB each (288 GB of HBM: wide slabs mean fewer, larger update gemms - at N = 13160 a slab of
         // 8192 queries gives 64 x 103 tiles per update, 13 rounds of the chip with a 4 % tail), between 8192 and 65536 queries
         m_slab = (int64_t)(((size_t)4 << 30) / ((size_t)pn * sizeof(double)));
         if (m_slab < 8192) m_slab = 8192;
@@ -271,9 +272,10 @@ extern "C" int mgpi_predict_var_dev(mgpi_ctx* ctx, const mgpi_mat* Xs, const mgp
     const int64_t rchunks = (pn + CN_ROWS - 1) / CN_ROWS;
     const size_t vbytes = (size_t)pn * m_slab * sizeof(double);
     const size_t pbytes = (size_t)rchunks * m_slab * sizeof(double);
-    MGPI_TRY(mgpi_ensure_work(ctx, vbytes + pbytes));
-    double* V = ctx->work;
-    double* partial = ctx->work + (size_t)pn * m_slab;
+    MGPI_TRY(mgpi_ensure_work(ctx, 2 * vbytes + pbytes));
+    double* V = ctx->work;                                  // K(x, xs_slab), updated in place by the sweep
+    double* Vs = ctx->work + (size_t)pn * m_slab;           // the solved rows L^-1 K(x, xs_slab) (see trsm_blocked, Xout)
+    double* partial = ctx->work + 2 * (size_t)pn * m_slab;
 
     for (int64_t q0 = 0; q0 < m; q0 += m_slab) {
         const int64_t mq = (m - q0 < m_slab) ? (m - q0) : m_slab;
@@ -281,9 +283,10 @@ extern "C" int mgpi_predict_var_dev(mgpi_ctx* ctx, const mgpi_mat* Xs, const mgp
         // V = K(x, xs_slab): rows = sources (padded rows written as 0), cols = queries
         MGPI_TRY(mgpi_launch_cov(ctx, t, X->d, X->ld, n, pn, Xs->d + q0 * Xs->ld, Xs->ld, mq, pq, 0, 0, 0, V, m_slab));
         // V <- L^-1 V
-        MGPI_TRY(mgpi_trsm_raw(ctx, L, V, m_slab, pq, 0, 1));     // variance path: inverse diagonal blocks allowed (chol.hip)
+        int in_vs = 0;
+        MGPI_TRY(mgpi_trsm_raw(ctx, L, V, m_slab, pq, 0, 1, Vs, &in_vs));     // variance path: inverse diagonal blocks allowed (chol.hip)
         dim3 grid((unsigned)((mq + 63) / 64), (unsigned)rchunks);
-        hipLaunchKernelGGL(colsq_kernel, grid, dim3(256), 0, ctx->stream, V, m_slab, pn, mq, partial);
+        hipLaunchKernelGGL(colsq_kernel, grid, dim3(256), 0, ctx->stream, in_vs ? Vs : V, m_slab, pn, mq, partial);
         MGPI_HIP_TRY(hipGetLastError());
         dim3 g2((unsigned)((mq + 255) / 256));
 #define MGPI_VF_CASE(DV)                                                                                         \
@@ -329,7 +332,7 @@ extern "C" int mgpi_condition_cov_dev(mgpi_ctx* ctx, const mgpi_mat* Xs, const m
     MGPI_TRY(mgpi_launch_cov(ctx, t, Xs->d, Xs->ld, m, pm, Xs->d, Xs->ld, m, pm, 1, 0, 0, cov->d, cov->ld));
     // V = L^-1 K(x, xs) (interpolators.py:157, transposed)
     MGPI_TRY(mgpi_launch_cov(ctx, t, X->d, X->ld, n, pn, Xs->d, Xs->ld, m, pm, 0, 0, 0, V, pm));
-    MGPI_TRY(mgpi_trsm_raw(ctx, L, V, pm, pm, 0, 1));
+    MGPI_TRY(mgpi_trsm_raw(ctx, L, V, pm, pm, 0, 1, nullptr, nullptr));
     // cov -= V^T V      (interpolators.py:199)
     return mgpi_launch_gemm(ctx, 1, 1, 0, pm, pm, pn, V, pm, V, pm, cov->d, cov->ld);
 }

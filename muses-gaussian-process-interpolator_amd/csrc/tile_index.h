@@ -75,6 +75,7 @@ struct gemm_stair {
     int on, P, p, Q, q, bi0, bj0, tpb;
     int nbands;
     int prefix[GEMM_STAIR_BANDS + 1];
+    int zero_c;          // the accumulators start from 0 instead of the C tile: C = -A B (rides along in this by-value argument)
 };
 
 
