@@ -13,6 +13,22 @@
 
 #include "panel_device.h"
 
+// Early returns (MGPI_TRY / MGPI_HIP_TRY) inside the look-ahead sections must not leave work running on the second stream
+// - or the ctx pointing at it - when the caller gets its error status back: armed on entry, disarmed on the success path.
+struct mgpi_stream_join_guard {
+    mgpi_ctx* c;
+    hipStream_t main;
+    bool armed;
+    ~mgpi_stream_join_guard() {
+        if (!armed) return;
+        c->stream = main;
+        c->lean = 0;
+        c->gemm_zero_c = 0;
+        if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+        (void)hipStreamSynchronize(main);
+    }
+};
+
 // 256 threads: FOUR lanes (one DPP quad) share row r of the block, lane part q owning columns [16q, 16q+16) in 16
 // registers (every register index is a compile-time constant after unrolling).  Column k: the owning parts drop
 // their entry of column k into LDS (rows above k write 0), one barrier, every lane reads the pivot and the 16
@@ -578,6 +594,7 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     };
 
     hipStream_t main_stream = ctx->stream;
+    mgpi_stream_join_guard join_on_error{ctx, main_stream, true};
     const bool lookahead = ctx->stream2 != nullptr && !ctx->no_lookahead;
     int64_t wc = super_width(0);
     mgpi_prof_begin(ctx, 1);
@@ -646,6 +663,7 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
                        keep_status);
     MGPI_HIP_TRY(hipGetLastError());
     K->factored = 1;          // mgpi_potrf_dev takes it back when the status says otherwise
+    join_on_error.armed = false;
     return 0;
 }
 
@@ -921,6 +939,7 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
             return 0;
         };
         hipStream_t main_stream = ctx->stream;
+        mgpi_stream_join_guard join_on_error{ctx, main_stream, true};
         const bool lookahead = ctx->stream2 != nullptr && !ctx->no_lookahead;
         int64_t wc = super_width(0);
         MGPI_TRY(solve_super(0, wc, false));
@@ -964,6 +983,7 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
             wc = w1;
         }
         if (lookahead && block_on_side) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
+        join_on_error.armed = false;
     } else {
         const int64_t nblk = (pn + nb - 1) / nb;
         for (int64_t b = nblk - 1; b >= 0; --b) {
@@ -1394,6 +1414,40 @@ extern "C" int mgpi_potrs(mgpi_ctx* ctx, const mgpi_mat* L, const double* b, int
 // ---- block-level entry points for the multi-GPU (2-D block-cyclic) driver ---------------------------------
 // A <- A L^-T for a factored diagonal block L (w x w) and a block of rows A (m x w): the panel trsm of the
 // right-looking factorisation, applied by the ranks that own the blocks below a remote diagonal block.
+// One 64-column step of  A <- A L^-T  in accumulator layout (panel_device.h), the multi-GPU counterpart of
+// panel_step_kernel: the factor is GIVEN (the diagonal block arrived by broadcast), so there is nothing to factor - a
+// column-role workgroup per 64 rows applies the previous step's columns to its rows of the current column block
+// (deferred right-looking update), builds the LDS images of the 64 x 64 diagonal sub-block and substitutes; update-role
+// workgroups apply the previous columns to the remaining column blocks.  One launch per step instead of two.
+__global__ __launch_bounds__(256, 2) void trsm_right_step_kernel(double* __restrict__ A, int64_t lda, int nrowblk,
+                                                                 const double* __restrict__ Lk, int64_t ldl, int64_t c0, int has_prev,
+                                                                 int rest_cols) {
+    __shared__ panel_lds s;
+    MGPI_CHAIN_PRIO();
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int64_t cp = c0 - IB, c1 = c0 + IB;
+    panel_double4_t acc[4];
+    if ((int)blockIdx.x >= nrowblk) {
+        const int t = (int)blockIdx.x - nrowblk, ti = t % nrowblk, tj = t / nrowblk;
+        double* C = A + ((int64_t)IB * ti) * lda + c1 + (int64_t)IB * tj;
+        panel_load(acc, C, lda, w, g, c, false);
+        panel_gemm_nt(acc, A + ((int64_t)IB * ti + 16 * w + c) * lda + cp + 2 * g, Lk + (c1 + (int64_t)IB * tj + c) * ldl + cp + 2 * g, ldl, 0, 4);
+        panel_store(acc, C, lda, w, g, c);
+        return;
+    }
+    const int64_t r0 = (int64_t)IB * blockIdx.x;
+    panel_load(acc, A + r0 * lda + c0, lda, w, g, c, false);
+    if (has_prev) panel_gemm_nt(acc, A + (r0 + 16 * w + c) * lda + cp + 2 * g, Lk + (c0 + c) * ldl + cp + 2 * g, ldl, 0, 4);
+    // images of the factored 64 x 64 diagonal sub-block: Lt[k][m] = L[m][k] (m >= k), 0 above; 1 / diagonal
+    for (int i = tid; i < IB * IB; i += 256) {
+        const int m = i >> 6, k = i & 63;                          // coalesced read of L[m][k]
+        s.Lt[k][m] = (m >= k) ? Lk[(c0 + m) * ldl + c0 + k] : 0.0;
+    }
+    if (tid < IB) s.invd[tid] = 1.0 / Lk[(c0 + tid) * ldl + c0 + tid];
+    __syncthreads();
+    trsm_acc_rounds<0>::run(acc, s, w, g, c, A + (r0 + 16 * w + c) * lda + c0);
+}
+
 extern "C" int mgpi_trsm_right_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* A) {
     MGPI_REQUIRE(ctx && L && A, "mgpi_trsm_right_dev: null pointer");
     MGPI_REQUIRE(L->rows == L->cols && A->cols == L->rows, "mgpi_trsm_right_dev: A has %lld columns, L is %lld x %lld",
@@ -1401,8 +1455,20 @@ extern "C" int mgpi_trsm_right_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* A
     MGPI_REQUIRE(L->rows % IB == 0 && A->prows % IB == 0, "mgpi_trsm_right_dev: dimensions must be multiples of %d", IB);
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
     const int64_t w = L->rows, m = A->prows;
+    static const bool step_kernel = getenv("MGPI_PANEL_STEP") ? atoi(getenv("MGPI_PANEL_STEP")) != 0 : true;
+    if (step_kernel && m / IB < 32768) {
+        const int nrowblk = (int)(m / IB);
+        for (int64_t c0 = 0; c0 < w; c0 += IB) {
+            const int has_prev = c0 > 0;
+            const int rest_cols = has_prev ? (int)((w - c0 - IB) / IB) : 0;
+            hipLaunchKernelGGL(trsm_right_step_kernel, dim3((unsigned)(nrowblk * (1 + rest_cols))), dim3(256), 0, ctx->stream, A->d, A->ld,
+                               nrowblk, L->d, L->ld, c0, has_prev, rest_cols);
+        }
+        MGPI_HIP_TRY(hipGetLastError());
+        return 0;
+    }
     // right-looking over the 64-column blocks, like the panel of the factorisation: the gemm on the chain has a
-    // contraction of 64 instead of up to w - 64
+    // contraction of 64 instead of up to w - 64  (the round-1 kernels, MGPI_PANEL_STEP=0)
     for (int64_t c0 = 0; c0 < w; c0 += IB) {
         MGPI_TRY(mgpi_launch_trsm_rows(ctx, L->d + c0 * L->ld + c0, L->ld, A->d + c0, A->ld, m));
         const int64_t c1 = c0 + IB;

@@ -255,3 +255,19 @@ def test_developer_switch_variants(env):
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'variant_worker.py')
     out = subprocess.run([sys.executable, worker], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and 'VARIANT-OK' in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize('m,w', [(64, 64), (640, 512), (1536, 256), (192, 128)])
+def test_trsm_right_block(ctx, m, w):
+    """A <- A L^-T with a factored diagonal block (the panel solve of the block-cyclic driver): one launch per 64 columns
+    in accumulator layout, against scipy; the strict upper triangle of L is never read"""
+    from scipy.linalg import solve_triangular
+    rng = np.random.default_rng(m + w)
+    L = np.tril(rng.standard_normal((w, w))) * 0.2 + np.diag(1.0 + rng.random(w))
+    A = rng.standard_normal((m, w))
+    Lg = L + np.triu(np.full((w, w), np.nan), 1)
+    dL, dA = dev(ctx, Lg), dev(ctx, A)
+    _lib.check(ctx.lib.mgpi_mat_mark_factored(dL.handle, 1))
+    _lib.check(ctx.lib.mgpi_trsm_right_dev(ctx.handle, dL.handle, dA.handle))
+    want = solve_triangular(L, A.T, lower=True).T
+    assert relmax(dA.to_host(), want) < 1e-12
