@@ -127,9 +127,12 @@ def syrk_launch_flops(n, nb=NB):
     return total
 
 
-def syrk_schedule_flops(n, nb=NB, panels=2, super_min=14336):
+def syrk_schedule_flops(n, nb=NB, panels=2, super_min=14336, merged_min=12288):
     """the same count for the shipped two-level schedule (csrc/chol.hip, super_width): the very first update is one
     panel wide, then `panels` panels per update while at least `super_min` rows would remain behind the super-panel.
+    While at least `merged_min` rows lie behind the NEXT super-panel the update is one merged launch over the whole
+    trailing matrix (next block column first, t (t + 1) wc flops); below that the block column is a gemm of its own on
+    the look-ahead stream and the launch covers the rest, t2 (t2 + 1) wc.  merged_min=None: the round-1 schedule.
     Cross-check for the number the library reports (mgpi_ctx_get_profile_flops); tests/ compare the two on the GPU."""
     pn = (n + 127) // 128 * 128
 
@@ -146,7 +149,9 @@ def syrk_schedule_flops(n, nb=NB, panels=2, super_min=14336):
         r1 = r0 + wc
         w1 = width(r1)
         t2 = t - w1
-        if t2 > 0:
+        if merged_min is not None and t2 >= merged_min and w1 % 128 == 0:
+            total += t * (t + 1.0) * wc
+        elif t2 > 0:
             total += t2 * (t2 + 1.0) * wc
         r0, wc = r1, w1
 

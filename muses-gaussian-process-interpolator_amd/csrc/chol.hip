@@ -596,6 +596,20 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     hipStream_t main_stream = ctx->stream;
     mgpi_stream_join_guard join_on_error{ctx, main_stream, true};
     const bool lookahead = ctx->stream2 != nullptr && !ctx->no_lookahead;
+    // Merged trailing update (round 2, second half).  The block column of super-panel k+1 used to be updated by a gemm of its
+    // own on the second stream, beside the main stream's update of the rest: a skinny launch (24.7 ms of stream time per
+    // factorisation at N = 32768 for 1.1e12 flops) that took CUs from the big one.  Now ONE launch per step updates the whole
+    // trailing matrix, the tiles of that block column first (merged_decode), and counts them on a device word as they are
+    // stored; the second stream waits for the count (hipStreamWaitValue32: ~1 us after the last tile, tools/waitvalue_probe.hip)
+    // and factors super-panel k+1 while the rest of the same launch runs.  Used while at least MGPI_MERGED_MIN rows trail
+    // (below that the chain is critical and the narrow-tile column update reaches the panel sooner); MGPI_POTRF_MERGED=0
+    // keeps the separate column update everywhere (developer switch, tested).
+    static const bool merged_on = getenv("MGPI_POTRF_MERGED") ? atoi(getenv("MGPI_POTRF_MERGED")) != 0 : true;
+    static const int64_t merged_min = getenv("MGPI_MERGED_MIN") ? atoll(getenv("MGPI_MERGED_MIN")) : 12288;
+    unsigned* d_sync = reinterpret_cast<unsigned*>(ctx->d_scal + 8064);
+    unsigned sync_target = 0;          // tiles counted so far in this factorisation: the word only grows until the next reset
+    bool merged_prev = false;          // did the previous step take the merged form (the second stream then owes no event wait)
+    if (lookahead && merged_on) MGPI_HIP_TRY(hipMemsetAsync(d_sync, 0, sizeof(unsigned), main_stream));
     int64_t wc = super_width(0);
     mgpi_prof_begin(ctx, 1);
     MGPI_TRY(factor_super(0, wc, false));
@@ -610,7 +624,27 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
         const int64_t w1 = super_width(r1);                  // super-panel k+1
         const double* P = A + r1 * lda + r0;                  // rows r1.., the w columns of super-panel k
         const int64_t t2 = t - w1;
-        if (lookahead) {
+        if (lookahead && merged_on && t2 > 0 && t2 >= merged_min && t % 128 == 0 && w1 % 128 == 0 && pn % 128 == 0) {
+            if (panel_on_side) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
+            // the first wait of a factorisation also orders the second stream behind the reset of the counter
+            if (!merged_prev) MGPI_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_upd, 0));
+            const int cw = (int)(w1 / 128);
+            sync_target += (unsigned)merged_column_tiles((int)(t / 128), cw);
+            MGPI_HIP_TRY(hipStreamWaitValue32(ctx->stream2, d_sync, sync_target, hipStreamWaitValueGte, 0xFFFFFFFFu));
+            ctx->stream = ctx->stream2;
+            int rc = factor_super(r1, w1, true);
+            ctx->stream = main_stream;
+            MGPI_TRY(rc);
+            MGPI_HIP_TRY(hipEventRecord(ctx->ev_panel, ctx->stream2));
+            panel_on_side = true;
+            mgpi_prof_begin(ctx, 0);
+            MGPI_TRY(mgpi_launch_syrk_merged(ctx, t, w, P, lda, A + r1 * lda + r1, lda, cw, d_sync));
+            mgpi_prof_end(ctx, 0);
+            mgpi_prof_flops(ctx, 0, (double)t * ((double)t + 1.0) * (double)w);
+            MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
+            merged_prev = true;
+        } else if (lookahead) {
+            merged_prev = false;
             // main stream: wait for super-panel k (before ev_panel is recorded again below)
             if (panel_on_side) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
             // second stream, enqueued first so that it gets the first free CUs:

@@ -253,7 +253,10 @@ struct gemm_no  { static constexpr bool v = false; };
 
 // ZEROC: the accumulators start from 0 and C is not read, C = -A B (a compile-time switch: as a run-time select in front of
 // the 64 accumulator loads it cost the trailing update 4 % - 0.86 -> 0.82 of peak isolated)
-template <bool BKM, bool LOWER, bool ZEROC = false>
+// MERGED (lower form only): the two-region tile order of merged_decode (tile_index.h); the workgroups of the first region -
+// the next panel's block column - announce their stored tile on st.mg_counter, which the look-ahead stream waits for
+// (hipStreamWaitValue32) instead of running that block column as a gemm of its own beside this kernel
+template <bool BKM, bool LOWER, bool ZEROC = false, bool MERGED = false>
 __global__ __launch_bounds__(256, 2) void gemm_f64_pipe_kernel(int64_t k, const double* __restrict__ A, int64_t lda,
                                                                const double* __restrict__ B, int64_t ldb,
                                                                double* __restrict__ C, int64_t ldc, int tiles_m,
@@ -264,12 +267,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_pipe_kernel(int64_t k, const 
     __shared__ __attribute__((aligned(16))) double lds[2 * (GA::doubles + GB::doubles)];
     constexpr int STAGE = GA::doubles + GB::doubles;
 
-    const int64_t bid = gemm_xcd_remap(blockIdx.x, ntiles);
     int ti, tj;
-    if (!LOWER && st.on) {
-        if (!gemm_stair_decode(st, bid, tiles_m, ti, tj)) return;
+    if constexpr (MERGED) {
+        merged_decode(blockIdx.x, tiles_m, st.mg_cw, st.mg_ncol, ntiles, ti, tj);
     } else {
-        tile_decode<LOWER>(bid, tiles_m, tiles_n, ti, tj);
+        const int64_t bid = gemm_xcd_remap(blockIdx.x, ntiles);
+        if (!LOWER && st.on) {
+            if (!gemm_stair_decode(st, bid, tiles_m, ti, tj)) return;
+        } else {
+            tile_decode<LOWER>(bid, tiles_m, tiles_n, ti, tj);
+        }
     }
     const int64_t m0 = (int64_t)ti * BM, n0 = (int64_t)tj * BN;
     const int tid = threadIdx.x;
@@ -352,16 +359,34 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_pipe_kernel(int64_t k, const 
     // epilogue: acc = -(C - A B).  The addresses are rebuilt from a laundered thread id (see the header comment).
     int tid2 = tid;
     asm volatile("" : "+v"(tid2));
-    {
-        const int lane2 = tid2 & 63, wave2 = tid2 >> 6;
-        double* c0 = C + (m0 + (wave2 >> 1) * WM + (lane2 >> 4)) * ldc + n0 + (wave2 & 1) * WN + (lane2 & 15);
+    const int lane2 = tid2 & 63, wave2 = tid2 >> 6;
+    double* c0 = C + (m0 + (wave2 >> 1) * WM + (lane2 >> 4)) * ldc + n0 + (wave2 & 1) * WN + (lane2 & 15);
+    if constexpr (MERGED) {
+        if ((int)blockIdx.x < st.mg_ncol) {       // workgroup-uniform: a tile of the next panel's block column
+            // Another stream's kernels read this tile as soon as the counter says so, on any XCD, while this kernel is still
+            // running - so the tile must be in memory, not dirty in this XCD's L2.  A release fence would do that by writing
+            // back the WHOLE L2 (buffer_wbl2), once per workgroup: measured 4 ms per factorisation at N = 32768.  Instead the
+            // tile is stored write-through (agent-scope relaxed atomic stores = global_store sc1) and the count is bumped
+            // once every wave's stores have been acknowledged.
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j)
+                for (int j = 0; j < FN; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) c0[(i * 16 + 4 * r) * ldc + j * 16] = -acc[i][j][r];
+                    for (int r = 0; r < 4; ++r)
+                        __hip_atomic_store(&c0[(i * 16 + 4 * r) * ldc + j * 16], -acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid2 == 0) __hip_atomic_fetch_add(st.mg_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
     }
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c0[(i * 16 + 4 * r) * ldc + j * 16] = -acc[i][j][r];
 }
 
 // ---- ping-pong variant: two 4-wave groups per 512-thread workgroup, one workgroup per CU ----------------------
@@ -530,6 +555,25 @@ static int launch_pipe(mgpi_ctx* ctx, int64_t m, int64_t n, int64_t k, const dou
     else
         hipLaunchKernelGGL((gemm_f64_pipe_kernel<BKM, LOWER>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, k, A, lda, B, ldb,
                            C, ldc, (int)tm, (int)tn, ntiles, st);
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// A22 (t x t, lower tiles) -= P P^T with the first `cw` tile columns first; *counter grows by merged_column_tiles(t/128, cw)
+// as those tiles complete.  The shape of the Cholesky trailing update with the next panel's block column folded in.
+int mgpi_launch_syrk_merged(mgpi_ctx* ctx, int64_t t, int64_t k, const double* P, int64_t ldp, double* C, int64_t ldc, int cw,
+                            unsigned* counter) {
+    MGPI_REQUIRE(t % 128 == 0 && k % GEMM_BK == 0 && cw >= 1 && (int64_t)cw * 128 < t && counter != nullptr,
+                 "merged syrk: t=%lld k=%lld cw=%d", (long long)t, (long long)k, cw);
+    MGPI_REQUIRE(((uintptr_t)P % 16 == 0) && ldp % 2 == 0, "merged syrk: operand must be 16-byte aligned with an even leading dimension");
+    const int64_t tm = t / 128, ntiles = tm * (tm + 1) / 2;
+    MGPI_REQUIRE(ntiles < (int64_t)2147483647, "merged syrk: tile count %lld out of range", (long long)ntiles);
+    gemm_stair st = no_stair();
+    st.mg_cw = cw;
+    st.mg_ncol = (int)merged_column_tiles((int)tm, cw);
+    st.mg_counter = counter;
+    hipLaunchKernelGGL((gemm_f64_pipe_kernel<false, true, false, true>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, k, P, ldp, P,
+                       ldp, C, ldc, (int)tm, (int)tm, ntiles, st);
     MGPI_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -86,6 +86,19 @@ int main() {
                           (long long)gr, (long long)gc, P, Q, p, q);
                 }
             }
+    // merged trailing update: the first region is exactly the first cw tile columns, the two regions together the whole triangle
+    for (int tm = 2; tm <= 45; ++tm)
+        for (int cw = 1; cw <= 8 && cw < tm; ++cw) {
+            const int64_t nt = (int64_t)tm * (tm + 1) / 2, ncol = merged_column_tiles(tm, cw);
+            std::set<std::pair<int, int>> seen;
+            for (int64_t b = 0; b < nt; ++b) {
+                int ti, tj;
+                merged_decode(b, tm, cw, ncol, nt, ti, tj);
+                CHECK(ti >= 0 && ti < tm && tj >= 0 && tj <= ti, "merged_decode(%lld; %d, %d) = (%d, %d)", (long long)b, tm, cw, ti, tj);
+                CHECK((tj < cw) == (b < ncol), "merged_decode: tile (%d, %d) in the wrong region (tm %d, cw %d)", ti, tj, tm, cw);
+                CHECK(seen.insert({ti, tj}).second, "merged_decode repeats (%d, %d)", ti, tj);
+            }
+        }
     // update-role tiles of the panel step: column block by column block, lower part
     for (int nrows1 = 1; nrows1 <= 40; ++nrows1)
         for (int rest = 0; rest <= 7 && rest <= nrows1; ++rest) {

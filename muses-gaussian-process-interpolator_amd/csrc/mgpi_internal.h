@@ -38,7 +38,7 @@ struct mgpi_ctx {
     mgpi_prof_slot* prof;         // [MGPI_PROF_SLOTS]: 0 trailing update (lower syrk), 1 panel, 2 whole potrf, 3 next-panel
                                   // column update, 4 big update of the multi-rhs forward solve (variance), 5 fused predict mean
     int* d_info;                  // device: first failing pivot (0 = none)
-    double* d_scal;               // device scratch, 8192 doubles: [0] logdet, [1] status accumulator, [64, 64 + 64*64 + 64) panel images, [8000] barrier token
+    double* d_scal;               // device scratch, 8192 doubles: [0] logdet, [1] status accumulator, [64, 64 + 64*64 + 64) panel images, [8000] barrier token, [8064] progress counter of the merged trailing update
     double* d_diag;               // diag(K) before factoring (pivot threshold), grown on demand
     int64_t diag_len;
     double* work;                 // device workspace, grown on demand
@@ -129,6 +129,10 @@ int mgpi_launch_gemm(mgpi_ctx* ctx, int a_kmajor, int b_kmajor, int lower_only,
                      int64_t m, int64_t n, int64_t k,
                      const double* A, int64_t lda, const double* B, int64_t ldb,
                      double* C, int64_t ldc);
+
+// trailing update with the next panel's block column first (gemm.hip, chol.hip): C (t x t, lower tiles) -= P P^T
+int mgpi_launch_syrk_merged(mgpi_ctx* ctx, int64_t t, int64_t k, const double* P, int64_t ldp, double* C, int64_t ldc, int cw,
+                            unsigned* counter);
 
 int mgpi_launch_cov(mgpi_ctx* ctx, const mgpi_terms_dev& t,
                     const double* x1, int64_t ldx1, int64_t n1, int64_t p1,

@@ -76,6 +76,10 @@ struct gemm_stair {
     int nbands;
     int prefix[GEMM_STAIR_BANDS + 1];
     int zero_c;          // the accumulators start from 0 instead of the C tile: C = -A B (rides along in this by-value argument)
+    // merged trailing update (chol.hip): the first mg_ncol workgroups own the tiles of the first mg_cw tile columns - the next
+    // panel's block column - and each bumps *mg_counter once its tile is stored
+    int mg_cw, mg_ncol;
+    unsigned* mg_counter;
 };
 
 
@@ -115,6 +119,30 @@ MGPI_HD bool gemm_stair_decode(const gemm_stair& st, int64_t bid, int tiles_m, i
 MGPI_HD int64_t gemm_xcd_remap(int64_t bid, int64_t ntiles) {
     const int64_t q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, loc = bid / 8;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+// Merged trailing update: the lower triangle of a tm x tm tile grid in TWO regions, the first cw tile columns first.
+//   workgroups [0, ncol): the tiles (i, j), j < cw, j <= i - the top cw x cw triangle, then the rows below it row by row
+//   workgroups [ncol, ntiles): the lower triangle of the remaining (tm - cw) tile rows / columns in the banded order above
+// Each region gets its own XCD split: workgroups b, b + 8, .. share an XCD whatever the region, so a region's list is
+// dealt to the XCDs in contiguous runs.  The first region is dispatched (hence finished) first.
+inline int64_t merged_column_tiles(int tm, int cw) { return (int64_t)cw * (cw + 1) / 2 + (int64_t)(tm - cw) * cw; }
+MGPI_HD void merged_decode(int64_t bid, int tm, int cw, int64_t ncol, int64_t ntiles, int& ti, int& tj) {
+    if (bid < ncol) {
+        int64_t idx = gemm_xcd_remap(bid, ncol);
+        const int64_t tri = (int64_t)cw * (cw + 1) / 2;
+        if (idx < tri) {
+            tri_decode(idx, ti, tj);
+        } else {
+            idx -= tri;
+            ti = cw + (int)(idx / cw);
+            tj = (int)(idx % cw);
+        }
+    } else {
+        tile_decode<true>(gemm_xcd_remap(bid - ncol, ntiles - ncol), tm - cw, tm - cw, ti, tj);
+        ti += cw;
+        tj += cw;
+    }
 }
 
 // update-role workgroup t of panel_step_kernel (chol.hip) -> tile (ti, tj), ti >= tj, column blocks tj < rest_cols,
