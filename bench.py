@@ -127,13 +127,12 @@ def syrk_launch_flops(n, nb=NB):
     return total
 
 
-def syrk_schedule_flops(n, nb=NB, panels=2, super_min=14336, merged_min=12288):
-    """the same count for the shipped two-level schedule (csrc/chol.hip, super_width): the very first update is one
-    panel wide, then `panels` panels per update while at least `super_min` rows would remain behind the super-panel.
-    While at least `merged_min` rows lie behind the NEXT super-panel the update is one merged launch over the whole
-    trailing matrix (next block column first, t (t + 1) wc flops); below that the block column is a gemm of its own on
-    the look-ahead stream and the launch covers the rest, t2 (t2 + 1) wc.  merged_min=None: the round-1 schedule.
-    Cross-check for the number the library reports (mgpi_ctx_get_profile_flops); tests/ compare the two on the GPU."""
+def syrk_schedule_launches(n, nb=NB, panels=2, super_min=14336, merged_min=12288):
+    """the trailing-update launches of the shipped two-level schedule (csrc/chol.hip, super_width) as (rows, contraction)
+    pairs: the very first update is one panel wide, then `panels` panels per update while at least `super_min` rows would
+    remain behind the super-panel.  While at least `merged_min` rows lie behind the NEXT super-panel the update is one
+    merged launch over the whole trailing matrix (next block column first, t rows); below that the block column is a gemm
+    of its own on the look-ahead stream and the launch covers the rest, t2 rows.  merged_min=None: the round-1 schedule."""
     pn = (n + 127) // 128 * 128
 
     def width(c0):
@@ -141,19 +140,25 @@ def syrk_schedule_flops(n, nb=NB, panels=2, super_min=14336, merged_min=12288):
         w = panels * nb if (c0 > 0 and left - panels * nb >= super_min) else nb
         return min(w, left)
 
-    total, r0, wc = 0.0, 0, width(0)
+    out, r0, wc = [], 0, width(0)
     while True:
         t = pn - r0 - wc
         if t <= 0:
-            return total
+            return out
         r1 = r0 + wc
         w1 = width(r1)
         t2 = t - w1
-        if merged_min is not None and t2 >= merged_min and w1 % 128 == 0:
-            total += t * (t + 1.0) * wc
+        if merged_min is not None and t2 > 0 and t2 >= merged_min and w1 % 128 == 0:
+            out.append((t, wc))
         elif t2 > 0:
-            total += t2 * (t2 + 1.0) * wc
+            out.append((t2, wc))
         r0, wc = r1, w1
+
+
+def syrk_schedule_flops(n, **kw):
+    """algorithmic lower-syrk flops of those launches, sum t (t + 1) wc: cross-check for the number the library reports
+    (mgpi_ctx_get_profile_flops); tests/ compare the two on the GPU"""
+    return float(sum(t * (t + 1.0) * wc for t, wc in syrk_schedule_launches(n, **kw)))
 
 
 class GpuStep(object):

@@ -193,6 +193,12 @@ __global__ __launch_bounds__(256) void potf2_trsm_kernel(double* __restrict__ A,
 // Measured and dropped: folding the PREVIOUS panel's trailing update (contraction 512) into the column role, to take the
 // skinny column-update gemm off the chain - with operands streamed straight from L2 the 64 x 64 x 512 products per
 // workgroup made a step 2x slower (N = 8192: potrf 13.8 ms against 7.5).
+// `has_prev` counts the previous 64-column blocks a column-role workgroup applies: 1 = the right-looking form above; j at step
+// j = LEFT-looking (every earlier block of the panel, no update-role workgroups at all).  Meant for large panels: their
+// chain is not critical, and the right-looking update's 64 x 64 x 64 tiles - each reads and rewrites a 32 KB tile of the
+// panel for half a megaflop, thousands of workgroups per step - cost the trailing update that runs beside them 8 ms per
+// factorisation at N = 32768 (measured by leaving them out).  Measured: no gain (the products from L2 cost the same), so
+// this form is a tested variant, off by default; sub-panels (MGPI_PANEL_INNER) are what helped.
 // `mode` splits the work for LARGE panels, where hundreds of workgroups repeating the 64 x 64 factorisation would take CU
 // time from the trailing update that runs beside the panel:
 //   mode 0  everything in one launch (every column-role workgroup factors the diagonal block itself)
@@ -230,7 +236,8 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__
     const int64_t r0 = c0 + (int64_t)IB * b;                      // this workgroup's rows
     if (b > 0) {
         panel_load(acc, A + r0 * lda + c0, lda, w, g, c, false);
-        if (has_prev) panel_gemm_nt(acc, A + (r0 + 16 * w + c) * lda + cp + 2 * g, A + (c0 + c) * lda + cp + 2 * g, lda, 0, 4);
+        for (int64_t kk = c0 - (int64_t)IB * has_prev; kk < c0; kk += IB)
+            panel_gemm_nt(acc, A + (r0 + 16 * w + c) * lda + kk + 2 * g, A + (c0 + c) * lda + kk + 2 * g, lda, 0, 4);
     }
     if (mode == 2) {
         for (int i = tid; i < IB * IB; i += 256) (&s.Lt[0][0])[i] = F[i];
@@ -240,7 +247,8 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__
         // the diagonal block, current as of the previous step
         panel_double4_t accD[4];
         panel_load(accD, A + c0 * lda + c0, lda, w, g, c, true);
-        if (has_prev) panel_gemm_nt(accD, A + (c0 + 16 * w + c) * lda + cp + 2 * g, A + (c0 + c) * lda + cp + 2 * g, lda, 0, w + 1);
+        for (int64_t kk = c0 - (int64_t)IB * has_prev; kk < c0; kk += IB)
+            panel_gemm_nt(accD, A + (c0 + 16 * w + c) * lda + kk + 2 * g, A + (c0 + c) * lda + kk + 2 * g, lda, 0, w + 1);
         int bad = 0;
         potf2_acc_rounds<0>::run(accD, s, w, g, c, bad, b == 0 ? S : nullptr);
         if (b == 0) {
@@ -267,11 +275,12 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__
 
 // one step: diagonal block at (c0, c0) of the matrix A (c0 absolute), `rows_below` rows below the block, the panel ends at
 // column panel_end; has_prev: the columns [c0 - 64, c0) of this panel were solved by the previous step and still have to be
-// applied to everything right of them.  split: two launches (diagonal block, then the rows) instead of one
+// applied to everything right of them (left: has_prev earlier blocks of the panel are applied to this step's columns only, by the
+// column-role workgroups).  split: two launches (diagonal block, then the rows) instead of one
 static int launch_panel_step(mgpi_ctx* ctx, double* A, int64_t lda, int64_t c0, int has_prev, int64_t rows_below, int64_t panel_end,
-                             int64_t pivot_base, const double* diag0, double* S, bool split) {
+                             int64_t pivot_base, const double* diag0, double* S, bool split, bool left = false) {
     const int nfused = (int)(1 + rows_below / IB);
-    const int rest_cols = has_prev ? (int)((panel_end - c0 - IB) / IB) : 0;
+    const int rest_cols = (has_prev && !left) ? (int)((panel_end - c0 - IB) / IB) : 0;
     int64_t nrest = 0;
     for (int tj = 0; tj < rest_cols; ++tj) nrest += nfused - 1 - tj;       // tiles on/below the diagonal, rows >= c0 + 64
     double* F = ctx->d_scal + 64;                                          // 64 x 64 + 64 doubles of the ctx's scalar scratch
@@ -455,6 +464,20 @@ __global__ __launch_bounds__(256) void logdiag_kernel(const double* __restrict__
     if (threadIdx.x == 0) out[0] = accumulate ? out[0] + part[0] : part[0];
 }
 
+// One wave that returns once *counter has reached `want` (wrap-safe): how the look-ahead stream waits for PART of a kernel
+// that runs on the main stream.  hipStreamWaitValue32 does the same without a wave (measured equal: ~1 us from the last
+// increment to the next kernel's start, tools/waitvalue_probe.hip) but a factorisation that uses it never finishes under
+// rocprofv3 --pmc (tools/pmc_hang_probe.sh), so it is not used.  The producer is always submitted before this kernel, and the
+// poll is bounded: after 2^21 sleeps (~6 s) it gives up and flags the factorisation as failed (status -1) instead of hanging.
+__global__ void wait_count_kernel(const unsigned* __restrict__ counter, unsigned want, int* __restrict__ info) {
+    if (threadIdx.x != 0) return;
+    for (int guard = 0; guard < (1 << 21); ++guard) {
+        if ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) return;
+        __builtin_amdgcn_s_sleep(32);
+    }
+    atomicCAS(info, 0, -1);
+}
+
 // ---- the factorisation ----------------------------------------------------------------------------------
 // Enqueues the whole factorisation of K on ctx's streams and returns without a host synchronisation.
 //   pivot_base  global index of K's first row: a failing pivot k is reported as pivot_base + k (1-based)
@@ -520,13 +543,18 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     // larger panels: the same kernel as two launches per step (diagonal block, then the rows); MGPI_PANEL_STEP_SPLIT=0 leaves
     // them to the round-1 kernels
     static const bool step_split = getenv("MGPI_PANEL_STEP_SPLIT") ? atoi(getenv("MGPI_PANEL_STEP_SPLIT")) != 0 : true;
+    // left-looking steps (see panel_step_kernel): measured equal to the right-looking form at N = 32768 (188.7 against 188.5 ms:
+    // the j products per workgroup straight from L2 cost what the update-role tiles did), so off by default; kept as a
+    // tested variant (MGPI_PANEL_LEFT_ROWS = rows below the panel above which it applies)
+    static const int64_t left_rows = getenv("MGPI_PANEL_LEFT_ROWS") ? atoll(getenv("MGPI_PANEL_LEFT_ROWS")) : ((int64_t)1 << 40);
     int64_t strip_first = pn / IB;                      // first 64-block whose factored diagonal block waits in the scratch strip
     auto factor_panel = [&](int64_t r0, int64_t w) -> int {
         if (panel_step && (pn - r0 - IB <= step_rows || step_split)) {
             const bool split = pn - r0 - IB > step_rows;
+            const bool left = pn - r0 - IB > left_rows;          // left-looking inside large panels (see panel_step_kernel)
             for (int64_t c0 = r0; c0 < r0 + w; c0 += IB) {
-                MGPI_TRY(launch_panel_step(ctx, A, lda, c0, c0 > r0, pn - c0 - IB, r0 + w, pivot_base + c0, ctx->d_diag + c0,
-                                           ctx->d_diag + ctx->diag_len + c0 * IB, split));
+                MGPI_TRY(launch_panel_step(ctx, A, lda, c0, left ? (int)((c0 - r0) / IB) : (c0 > r0 ? 1 : 0), pn - c0 - IB, r0 + w,
+                                           pivot_base + c0, ctx->d_diag + c0, ctx->d_diag + ctx->diag_len + c0 * IB, split, left));
                 if (c0 / IB < strip_first) strip_first = c0 / IB;
             }
             return 0;
@@ -570,7 +598,15 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     // write disjoint columns and both only read super-panel k.  So the main stream sees one big lower-triangular
     // update after another.  Events: ev_upd = "the rest of step k-1 is done" (its columns include the ones the second
     // stream updates next), ev_panel = "super-panel k+1 is factored".
+    // Large panels are factored as sub-panels of MGPI_PANEL_INNER columns with a gemm between them: inside a (sub-)panel the
+    // update is right-looking in 64-column steps of contraction 64 (short chain, but every step rewrites the rest of the
+    // panel through 64 x 64 x 64 tiles straight from L2), between sub-panels it is one LDS-staged gemm of contraction
+    // MGPI_PANEL_INNER.  Used while more than MGPI_PANEL_INNER_ROWS rows lie below the panel, where the chain is not critical.
+    // N = 32768: potrf 188.1 ms with 512 (no sub-panels), 186.3 with 256, 187.2 with 128.
+    static const int64_t inner_w = getenv("MGPI_PANEL_INNER") ? atoll(getenv("MGPI_PANEL_INNER")) : 256;
+    static const int64_t inner_rows = getenv("MGPI_PANEL_INNER_ROWS") ? atoll(getenv("MGPI_PANEL_INNER_ROWS")) : 8192;
     auto factor_super = [&](int64_t c0, int64_t wc, bool on_side) -> int {
+        const int64_t nb = (inner_w >= IB && inner_w % IB == 0 && inner_w < ctx->nb && pn - c0 - wc > inner_rows) ? inner_w : ctx->nb;
         for (int64_t p0 = c0; p0 < c0 + wc; p0 += nb) {
             const int64_t w = (c0 + wc - p0 < nb) ? (c0 + wc - p0) : nb;
             ctx->lean = on_side ? 1 : 0;
@@ -600,11 +636,14 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     // own on the second stream, beside the main stream's update of the rest: a skinny launch (24.7 ms of stream time per
     // factorisation at N = 32768 for 1.1e12 flops) that took CUs from the big one.  Now ONE launch per step updates the whole
     // trailing matrix, the tiles of that block column first (merged_decode), and counts them on a device word as they are
-    // stored; the second stream waits for the count (hipStreamWaitValue32: ~1 us after the last tile, tools/waitvalue_probe.hip)
+    // stored; the second stream waits for the count (wait_count_kernel: ~1 us after the last tile, tools/waitvalue_probe.hip)
     // and factors super-panel k+1 while the rest of the same launch runs.  Used while at least MGPI_MERGED_MIN rows trail
     // (below that the chain is critical and the narrow-tile column update reaches the panel sooner); MGPI_POTRF_MERGED=0
     // keeps the separate column update everywhere (developer switch, tested).
-    static const bool merged_on = getenv("MGPI_POTRF_MERGED") ? atoi(getenv("MGPI_POTRF_MERGED")) != 0 : true;
+    // Under rocprofv3 --pmc (ROCPROF_COUNTER_COLLECTION=1) a profiled kernel runs ALONE on the GPU, so one that feeds a kernel
+    // running beside it can never do so: the separate column update is used there (same arithmetic).
+    static const bool counters = getenv("ROCPROF_COUNTER_COLLECTION") && atoi(getenv("ROCPROF_COUNTER_COLLECTION")) != 0;
+    static const bool merged_on = getenv("MGPI_POTRF_MERGED") ? atoi(getenv("MGPI_POTRF_MERGED")) != 0 : !counters;
     static const int64_t merged_min = getenv("MGPI_MERGED_MIN") ? atoll(getenv("MGPI_MERGED_MIN")) : 12288;
     unsigned* d_sync = reinterpret_cast<unsigned*>(ctx->d_scal + 8064);
     unsigned sync_target = 0;          // tiles counted so far in this factorisation: the word only grows until the next reset
@@ -626,22 +665,26 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
         const int64_t t2 = t - w1;
         if (lookahead && merged_on && t2 > 0 && t2 >= merged_min && t % 128 == 0 && w1 % 128 == 0 && pn % 128 == 0) {
             if (panel_on_side) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
+            // The producer goes into its queue BEFORE the consumers that wait for its count: a tool that serialises dispatches
+            // in submission order (rocprofv3 --pmc does) would otherwise hold this launch back behind kernels that cannot
+            // start without it.
+            const int cw = (int)(w1 / 128);
+            mgpi_prof_begin(ctx, 0);
+            MGPI_TRY(mgpi_launch_syrk_merged(ctx, t, w, P, lda, A + r1 * lda + r1, lda, cw, d_sync));
+            mgpi_prof_end(ctx, 0);
+            mgpi_prof_flops(ctx, 0, (double)t * ((double)t + 1.0) * (double)w);
             // the first wait of a factorisation also orders the second stream behind the reset of the counter
             if (!merged_prev) MGPI_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_upd, 0));
-            const int cw = (int)(w1 / 128);
+            MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
             sync_target += (unsigned)merged_column_tiles((int)(t / 128), cw);
-            MGPI_HIP_TRY(hipStreamWaitValue32(ctx->stream2, d_sync, sync_target, hipStreamWaitValueGte, 0xFFFFFFFFu));
+            hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(64), 0, ctx->stream2, d_sync, sync_target, ctx->d_info);
+            MGPI_HIP_TRY(hipGetLastError());
             ctx->stream = ctx->stream2;
             int rc = factor_super(r1, w1, true);
             ctx->stream = main_stream;
             MGPI_TRY(rc);
             MGPI_HIP_TRY(hipEventRecord(ctx->ev_panel, ctx->stream2));
             panel_on_side = true;
-            mgpi_prof_begin(ctx, 0);
-            MGPI_TRY(mgpi_launch_syrk_merged(ctx, t, w, P, lda, A + r1 * lda + r1, lda, cw, d_sync));
-            mgpi_prof_end(ctx, 0);
-            mgpi_prof_flops(ctx, 0, (double)t * ((double)t + 1.0) * (double)w);
-            MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
             merged_prev = true;
         } else if (lookahead) {
             merged_prev = false;
@@ -708,6 +751,11 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
     MGPI_HIP_TRY(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     MGPI_HIP_TRY(hipMemcpyAsync(&ld, ctx->d_scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (info < 0) {
+        K->factored = 0;
+        mgpi_set_error("mgpi_potrf_dev: the trailing update's progress counter was not reached (internal error)");
+        return MGPI_ERR_HIP;
+    }
     if (info != 0) {
         K->factored = 0;
         mgpi_set_error("covariance is not positive definite! (pivot %d is not above %.3g times its original diagonal entry)", info,
@@ -744,6 +792,10 @@ extern "C" int mgpi_ctx_status_read(mgpi_ctx* ctx, int64_t* pivot, double* logdi
     MGPI_HIP_TRY(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     MGPI_HIP_TRY(hipMemcpyAsync(&ld, ctx->d_scal + 1, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (info < 0) {
+        mgpi_set_error("mgpi_ctx_status_read: a trailing update's progress counter was not reached (internal error)");
+        return MGPI_ERR_HIP;
+    }
     if (pivot) *pivot = info;
     if (logdiag) *logdiag = ld;
     return 0;

@@ -255,7 +255,7 @@ struct gemm_no  { static constexpr bool v = false; };
 // the 64 accumulator loads it cost the trailing update 4 % - 0.86 -> 0.82 of peak isolated)
 // MERGED (lower form only): the two-region tile order of merged_decode (tile_index.h); the workgroups of the first region -
 // the next panel's block column - announce their stored tile on st.mg_counter, which the look-ahead stream waits for
-// (hipStreamWaitValue32) instead of running that block column as a gemm of its own beside this kernel
+// (wait_count_kernel, chol.hip) instead of running that block column as a gemm of its own beside this kernel
 template <bool BKM, bool LOWER, bool ZEROC = false, bool MERGED = false>
 __global__ __launch_bounds__(256, 2) void gemm_f64_pipe_kernel(int64_t k, const double* __restrict__ A, int64_t lda,
                                                                const double* __restrict__ B, int64_t ldb,
@@ -608,6 +608,11 @@ static int launch_shape(mgpi_ctx* ctx, int lower_only, int64_t m, int64_t n, int
     if (lower_only) {
         MGPI_REQUIRE(m == n && m % 128 == 0, "gemm(lower): needs m == n, multiple of 128 (got %lld x %lld)", (long long)m,
                      (long long)n);
+        // developer switch for counter runs: the merged form of the trailing update alone (its counter ticks, nobody waits)
+        static const int merged_cw = getenv("MGPI_SYRK_MERGED_CW") ? atoi(getenv("MGPI_SYRK_MERGED_CW")) : 0;
+        if constexpr (!AK && !BKM)
+            if (merged_cw > 0 && (int64_t)merged_cw * 128 < m && A == B && lda == ldb)
+                return mgpi_launch_syrk_merged(ctx, m, k, A, lda, C, ldc, merged_cw, reinterpret_cast<unsigned*>(ctx->d_scal + 8064));
         if (use_pp(m / 128 * (m / 128 + 1) / 2)) return launch_pp<AK, BKM, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
         if constexpr (!AK) if (use_pipe()) return launch_pipe<BKM, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
         if (use_glds()) return launch_one<128, 128, AK, BKM, true, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
