@@ -11,6 +11,14 @@
 #include <math.h>
 #include <vector>
 
+#ifdef PANEL_TRACE   // diagnostic build only
+#define PANEL_STAMPS 1
+#include <hip/hip_runtime.h>
+__device__ long long panel_stamps[8];
+extern "C" int mgpi_debug_read_stamps(long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(panel_stamps), sizeof(long long) * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 #include "panel_device.h"
 
 // Early returns (MGPI_TRY / MGPI_HIP_TRY) inside the look-ahead sections must not leave work running on the second stream
@@ -206,12 +214,34 @@ __global__ __launch_bounds__(256) void potf2_trsm_kernel(double* __restrict__ A,
 //   mode 2  the rest: column-role workgroups for the row blocks BELOW the diagonal block read the images from F
 //           instead of factoring, plus the update-role workgroups
 #define PANEL_F_DOUBLES (IB * IB + IB)
+#ifdef PANEL_TRACE   // diagnostic build only (tools/contention_probe.py): per-workgroup phase stamps of the step kernels
+__device__ unsigned long long g_panel_trace[1 << 18];
+__device__ unsigned g_panel_trace_n;
+extern "C" int mgpi_debug_read_trace(unsigned long long* host, unsigned* n) {
+    if (hipMemcpyFromSymbol(n, HIP_SYMBOL(g_panel_trace_n), sizeof(unsigned)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_panel_trace), sizeof(unsigned long long) * (1 << 18)) != hipSuccess) return -1;
+    unsigned zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_panel_trace_n), &zero, sizeof(unsigned)) != hipSuccess) return -1;
+    return 0;
+}
+#define PT_STAMP(k) do { if (threadIdx.x == 0) pt[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PT_FLUSH(role) do { if (threadIdx.x == 0) { const unsigned slot = atomicAdd(&g_panel_trace_n, 1u); if (slot < (1u << 18) / 8) { \
+    unsigned long long* o = g_panel_trace + 8 * slot; o[0] = (unsigned long long)c0; o[1] = ((unsigned long long)(role) << 32) | blockIdx.x; \
+    o[2] = pt[0]; o[3] = pt[1]; o[4] = pt[2]; o[5] = pt[3]; o[6] = nfused; o[7] = __builtin_amdgcn_s_memrealtime(); } } } while (0)
+#else
+#define PT_STAMP(k) do { } while (0)
+#define PT_FLUSH(role) do { } while (0)
+#endif
 __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__ A, int64_t lda, int64_t c0, int has_prev, int nfused,
                                                          int rest_cols, int64_t pivot_base, const double* __restrict__ diag0,
                                                          int* __restrict__ info, double* __restrict__ S, double ptol, int mode,
                                                          double* __restrict__ F, int64_t strideA, int64_t strideS, int64_t strideD) {
     __shared__ panel_lds s;
     MGPI_CHAIN_PRIO();
+#ifdef PANEL_TRACE
+    unsigned long long pt[4] = {0, 0, 0, 0};
+#endif
+    PT_STAMP(0);
     // strided batch (mgpi_loglikelihood_batch): problem y = blockIdx.y has its own matrix, scratch strip, original diagonal
     // and status word; single problems pass a 1-deep grid
     A += (int64_t)blockIdx.y * strideA;
@@ -229,7 +259,9 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__
         double* C = A + (c1 + (int64_t)IB * ti) * lda + c1 + (int64_t)IB * tj;
         panel_load(acc, C, lda, w, g, c, false);
         panel_gemm_nt(acc, A + (c1 + (int64_t)IB * ti + 16 * w + c) * lda + cp + 2 * g, A + (c1 + (int64_t)IB * tj + c) * lda + cp + 2 * g, lda, 0, 4);
+        PT_STAMP(1);
         panel_store(acc, C, lda, w, g, c);
+        PT_FLUSH(2);
         return;
     }
     const int b = (int)blockIdx.x + first_fused;
@@ -250,7 +282,9 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__
         for (int64_t kk = c0 - (int64_t)IB * has_prev; kk < c0; kk += IB)
             panel_gemm_nt(accD, A + (c0 + 16 * w + c) * lda + kk + 2 * g, A + (c0 + c) * lda + kk + 2 * g, lda, 0, w + 1);
         int bad = 0;
+        PT_STAMP(1);
         potf2_acc_rounds<0>::run(accD, s, w, g, c, bad, b == 0 ? S : nullptr);
+        PT_STAMP(2);
         if (b == 0) {
             if (tid == 0 && bad != 0) {
                 const int cand = (int)(pivot_base + bad);
@@ -266,11 +300,14 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__
                 for (int i = tid; i < IB * IB; i += 256) F[i] = (&s.Lt[0][0])[i];
                 if (tid < IB) F[IB * IB + tid] = s.invd[tid];
             }
+            PT_FLUSH(0);
             return;
         }
     }
     __syncthreads();                                               // the factor's LDS images are complete
     trsm_acc_rounds<0>::run(acc, s, w, g, c, A + (r0 + 16 * w + c) * lda + c0);
+    PT_STAMP(3);
+    PT_FLUSH(1);
 }
 
 // one step: diagonal block at (c0, c0) of the matrix A (c0 absolute), `rows_below` rows below the block, the panel ends at

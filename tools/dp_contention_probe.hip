@@ -1,0 +1,167 @@
+// developer probe: what does a latency-bound wave pay for sharing its SIMD with a wave that issues fp64 MFMAs back to back?
+// Stream A: an MFMA loop on every SIMD of the chip (256 or 512 workgroups of 4 waves).  Stream B (high priority): ONE workgroup of
+// four waves, each running a dependent chain of (a) v_fma_f64, (b) v_add_u32, (c) ds_read round trips, (d) v_mfma_f64 (dependent),
+// with and without s_setprio 3.  Reports cycles per dependent operation alone and beside the MFMA load.
+//   hipcc --offload-arch=gfx950 -O2 tools/dp_contention_probe.hip -o tools/dp_contention_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+typedef double double4_t __attribute__((ext_vector_type(4)));
+#define MFMA_V(acc, a, b) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+// 64 KB of LDS per workgroup: at most two per CU, so 256 (512) workgroups put one (two) MFMA waves on EVERY SIMD of the chip.
+// mem != nullptr: every iteration also streams 16 bytes per lane from a large buffer (the real kernel's global_load traffic)
+// where a wave runs: XCC id (HW_REG_XCC_ID = 20) in the high half, HW_REG_HW_ID (= 4: simd [5:4], cu [11:8], sh [12], se [15:13]) in the low
+__device__ __forceinline__ unsigned where_am_i() {
+    const unsigned hw = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4);
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);
+    return (xcc & 15) << 16 | (hw & 0xfff0);
+}
+__device__ unsigned g_load_where[4096];
+template <int LDS_MODE>
+__global__ __launch_bounds__(256) void load_kernel(int iters, const double* in, double* out, const double2* mem, size_t mem_mask) {
+    __shared__ double fill[8192];
+    if ((threadIdx.x & 63) == 0) g_load_where[(blockIdx.x * 4 + (threadIdx.x >> 6)) & 4095] = where_am_i();
+    for (int i = threadIdx.x; i < 8192; i += 256) fill[i] = 0.0;
+    __syncthreads();
+    double2 m = {0, 0};
+    size_t off = ((size_t)blockIdx.x * 256 + threadIdx.x) * 977;
+    double4_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+    double a0 = in[threadIdx.x], a1 = in[256 + threadIdx.x], b0 = a1 + 1, b1 = a0 - 1, b2 = a0 + a1, b3 = a0 - a1;
+    const double2* lds2 = reinterpret_cast<const double2*>(fill) + threadIdx.x;
+    double2 acc_l = {0, 0};
+    for (int it = 0; it < iters; ++it) {
+        if (LDS_MODE == 1 && (it & 3) == 0) {             // the real kernel's shape: 8 x 1 KB reads in one burst per 32 MFMAs
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const double2 v = lds2[256 * (q & 7)]; acc_l.x += v.x; acc_l.y += v.y; }
+        }
+        if (LDS_MODE == 2 && (it & 1) == 0) {             // the same bytes, two reads per 8 MFMAs
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { const double2 v = lds2[256 * ((it + q) & 7)]; acc_l.x += v.x; acc_l.y += v.y; }
+        }
+        if (LDS_MODE == 3 && (it & 3) == 0) {             // VALU only: 16 fp64 adds per 32 MFMAs, no LDS
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { acc_l.x += a0; acc_l.y += a1; }
+        }
+        if (LDS_MODE == 4 && (it & 3) == 0) {             // LDS only: the reads land in registers nobody adds up
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const double2 v = lds2[256 * (q & 7)]; asm volatile("" :: "v"(v.x), "v"(v.y)); }
+        }
+        if (LDS_MODE == 5 && (it & 3) == 0) {             // burst of reads as in mode 1, the wave then yields the issue port for a moment
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const double2 v = lds2[256 * (q & 7)]; acc_l.x += v.x; acc_l.y += v.y; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        MFMA_V(c0, a0, b0); MFMA_V(c1, a0, b1); MFMA_V(c2, a0, b2); MFMA_V(c3, a0, b3);
+        MFMA_V(c4, a1, b0); MFMA_V(c5, a1, b1); MFMA_V(c6, a1, b2); MFMA_V(c7, a1, b3);
+        if (mem) {
+            const double2 v = mem[off & mem_mask];
+            m.x += v.x; m.y += v.y;
+            off += 256 * 1024 + 17;
+        }
+    }
+    double4_t s4 = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+    if (s4[0] + s4[1] + s4[2] + s4[3] + m.x + m.y + fill[threadIdx.x ^ 1] + acc_l.x + acc_l.y == 1.2345) out[0] = s4[0];
+}
+
+template <int MODE, bool PRIO>
+__global__ __launch_bounds__(256) void chain_kernel(int n, const double* in, double* out, unsigned long long* clk, const int* chase) {
+    __shared__ int ring[256];
+    if (PRIO) __builtin_amdgcn_s_setprio(3);
+    double a = in[threadIdx.x] * 1e-3, b = 1.0000001;
+    unsigned u = threadIdx.x;
+    ring[threadIdx.x] = (threadIdx.x + 1) & 255;
+    __syncthreads();
+    int p = threadIdx.x;
+    double4_t acc = {0, 0, 0, 0};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < n; ++i) {
+        if (MODE == 0) a = fma(a, b, 1e-9);
+        if (MODE == 1) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(u) : "v"(u)); }
+        if (MODE == 2) p = ring[p];
+        if (MODE == 3) MFMA_V(acc, a, b);
+        if (MODE == 4) p = chase[p];
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) { clk[threadIdx.x >> 6] = t1 - t0; clk[4 + (threadIdx.x >> 6)] = where_am_i(); }
+    if (a + u + p + acc[0] == 1.2345) out[0] = a;
+}
+
+static unsigned g_chain_where = 0;
+template <int MODE, bool PRIO>
+double chain(hipStream_t s, int n, const double* din, double* dout, unsigned long long* dclk, const int* chase) {
+    hipLaunchKernelGGL((chain_kernel<MODE, PRIO>), dim3(1), dim3(256), 0, s, n, din, dout, dclk, chase);
+    CHECK(hipStreamSynchronize(s));
+    unsigned long long h[8];
+    CHECK(hipMemcpy(h, dclk, 64, hipMemcpyDeviceToHost));
+    g_chain_where = (unsigned)h[4];
+    return (double)(h[0] + h[1] + h[2] + h[3]) / 4.0 / n;
+}
+
+int main() {
+    double *din, *dout;
+    unsigned long long* dclk;
+    CHECK(hipMalloc(&din, 512 * 8)); CHECK(hipMalloc(&dout, 64)); CHECK(hipMalloc(&dclk, 64));
+    std::vector<double> h(512, 0.5);
+    CHECK(hipMemcpy(din, h.data(), 512 * 8, hipMemcpyHostToDevice));
+    hipStream_t sa, sb;
+    int lo, hi;
+    CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    CHECK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+    CHECK(hipStreamCreateWithPriority(&sb, hipStreamNonBlocking, hi));
+    const int n = 4000;
+    // pointer chase through a 64 MB table (L2 misses, Infinity Cache / HBM latency) and the streaming buffer of the load
+    const size_t chase_n = (size_t)16 << 20;
+    int* chase;
+    CHECK(hipMalloc(&chase, chase_n * 4));
+    {
+        std::vector<int> hc(chase_n);
+        for (size_t i = 0; i < chase_n; ++i) hc[i] = (int)((i * 2654435761ull + 12345) % chase_n);
+        CHECK(hipMemcpy(chase, hc.data(), chase_n * 4, hipMemcpyHostToDevice));
+    }
+    const size_t mem_n = (size_t)1 << 28;                   // 2^28 double2 = 4 GB
+    double2* mem;
+    CHECK(hipMalloc(&mem, mem_n * 16));
+    CHECK(hipMemset(mem, 0, mem_n * 16));
+    const char* names[5] = {"dependent v_fma_f64", "dependent v_add_u32", "dependent ds_read", "dependent v_mfma_f64_16x16x4", "dependent global load (64 MB table)"};
+    for (int load = 0; load < 10; ++load) {                 // 0: idle chip; 1, 2: one / two MFMA waves per SIMD; 3, 4: the same + streaming loads; 5, 6: two waves + LDS reads (burst / spread)
+        const int waves = load == 0 ? 0 : (load >= 5 ? 2 : (load - 1) % 2 + 1);
+        if (load == 7) hipLaunchKernelGGL(load_kernel<3>, dim3(512), dim3(256), 0, sa, 400000, din, dout, (const double2*)nullptr, mem_n - 1);
+        if (load == 8) hipLaunchKernelGGL(load_kernel<4>, dim3(512), dim3(256), 0, sa, 400000, din, dout, (const double2*)nullptr, mem_n - 1);
+        if (load == 9) hipLaunchKernelGGL(load_kernel<5>, dim3(512), dim3(256), 0, sa, 400000, din, dout, (const double2*)nullptr, mem_n - 1);
+        const bool with_mem = load == 3 || load == 4;
+        if (load) {
+            if (load >= 7) { }
+            else if (load == 5) hipLaunchKernelGGL(load_kernel<1>, dim3(512), dim3(256), 0, sa, 400000, din, dout, (const double2*)nullptr, mem_n - 1);
+            else if (load == 6) hipLaunchKernelGGL(load_kernel<2>, dim3(512), dim3(256), 0, sa, 400000, din, dout, (const double2*)nullptr, mem_n - 1);
+            else hipLaunchKernelGGL(load_kernel<0>, dim3(256 * waves), dim3(256), 0, sa, with_mem ? 150000 : 400000, din, dout, with_mem ? mem : nullptr, mem_n - 1);
+            hipLaunchKernelGGL((chain_kernel<0, false>), dim3(1), dim3(256), 0, sb, 100, din, dout, dclk, chase);   // let the load start
+            CHECK(hipStreamSynchronize(sb));
+        }
+        double r[5][2];
+        r[0][0] = chain<0, false>(sb, n, din, dout, dclk, chase); r[0][1] = chain<0, true>(sb, n, din, dout, dclk, chase);
+        r[1][0] = chain<1, false>(sb, n, din, dout, dclk, chase); r[1][1] = chain<1, true>(sb, n, din, dout, dclk, chase);
+        r[2][0] = chain<2, false>(sb, n, din, dout, dclk, chase); r[2][1] = chain<2, true>(sb, n, din, dout, dclk, chase);
+        r[3][0] = chain<3, false>(sb, n, din, dout, dclk, chase); r[3][1] = chain<3, true>(sb, n, din, dout, dclk, chase);
+        r[4][0] = chain<4, false>(sb, n, din, dout, dclk, chase); r[4][1] = chain<4, true>(sb, n, din, dout, dclk, chase);
+        hipError_t q = hipStreamQuery(sa);
+        printf("load: %d MFMA wave(s) per SIMD%s%s\n", waves, with_mem ? " + 16 B per lane per 8 MFMAs streamed from a 4 GB buffer" : load == 5 ? " + 8 ds_read_b128 in a burst per 32 MFMAs" : load == 6 ? " + 2 ds_read_b128 per 8 MFMAs" : load == 7 ? " + 16 v_add_f64 per 32 MFMAs, no LDS" : load == 8 ? " + 8 ds_read_b128 per 32 MFMAs, results unused" : load == 9 ? " + burst of 8 reads and adds, then s_sleep 1" : "",
+               load ? (q == hipErrorNotReady ? " (still running: the chains ran beside it)" : " (ALREADY FINISHED)") : "");
+        if (load) {
+            std::vector<unsigned> lw(4096);
+            CHECK(hipMemcpyFromSymbol(lw.data(), HIP_SYMBOL(g_load_where), 4096 * 4));
+            int same_cu = 0, same_simd = 0;
+            for (int i = 0; i < 256 * waves * 4; ++i) {
+                if ((lw[i] & 0xffffff00u) == (g_chain_where & 0xffffff00u)) ++same_cu;       // same XCC, SE, SH, CU (bits 7:6 are the pipe id)
+                if ((lw[i] & 0xffffff30u) == (g_chain_where & 0xffffff30u)) ++same_simd;
+            }
+            printf("   the last chain's wave 0 ran on xcc %u se %u sh %u cu %u simd %u: %d load waves on that CU, %d on that SIMD\n", g_chain_where >> 16,
+                   (g_chain_where >> 13) & 7, (g_chain_where >> 12) & 1, (g_chain_where >> 8) & 15, (g_chain_where >> 4) & 3, same_cu, same_simd);
+        }
+        for (int m = 0; m < 5; ++m) printf("   %-38s %7.1f cycles per op, %7.1f with s_setprio 3\n", names[m], r[m][0], r[m][1]);
+        CHECK(hipStreamSynchronize(sa));
+    }
+    return 0;
+}
