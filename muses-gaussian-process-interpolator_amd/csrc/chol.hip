@@ -508,6 +508,7 @@ __global__ __launch_bounds__(256) void logdiag_kernel(const double* __restrict__
 // poll is bounded: after 2^21 sleeps (~6 s) it gives up and flags the factorisation as failed (status -1) instead of hanging.
 __global__ void wait_count_kernel(const unsigned* __restrict__ counter, unsigned want, int* __restrict__ info) {
     if (threadIdx.x != 0) return;
+    if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) return;      // an earlier wait of this factorisation gave up
     for (int guard = 0; guard < (1 << 21); ++guard) {
         if ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) return;
         __builtin_amdgcn_s_sleep(32);
@@ -1041,7 +1042,9 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
         // blocks, i.e. with a contraction of 2048 (NN gemm alone at 32768 x 4096: 62 / 69 / 71 TFLOP/s for K = 512 / 1024 /
         // 2048).  C3 variance: 72.5 ms with 1 block per update, 71.1 with 2, 69.8 with 4, 72.1 with 8, 76.0 with 16.
         static const int64_t super_blocks = getenv("MGPI_TRSM_SUPER") ? atoll(getenv("MGPI_TRSM_SUPER")) : 4;
-        static const int64_t super_min = getenv("MGPI_TRSM_SUPER_MIN") ? atoll(getenv("MGPI_TRSM_SUPER_MIN")) : 8192;
+        // [r2b] the threshold below which the width drops back to one block: 8192 -> 2048 rows (C2 variance 6.02 -> 5.61 ms, C5
+        // 2.708 -> 2.671 s, C3 unchanged 70.6 -> 70.4 ms)
+        static const int64_t super_min = getenv("MGPI_TRSM_SUPER_MIN") ? atoll(getenv("MGPI_TRSM_SUPER_MIN")) : 2048;
         auto super_width = [&](int64_t r0) -> int64_t {
             const int64_t left = pn - r0;
             int64_t wc = (inv && r0 > 0 && left - super_blocks * nb >= super_min) ? super_blocks * nb : nb;
