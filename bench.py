@@ -127,13 +127,17 @@ def syrk_launch_flops(n, nb=NB):
     return total
 
 
-def syrk_schedule_launches(n, nb=NB, panels=2, super_min=14336, merged_min=12288):
+def syrk_schedule_launches(n, nb=NB, panels=2, super_min=14336, merged_min=12288, tail_rows=2048):
     """the trailing-update launches of the shipped two-level schedule (csrc/chol.hip, super_width) as (rows, contraction)
     pairs: the very first update is one panel wide, then `panels` panels per update while at least `super_min` rows would
     remain behind the super-panel.  While at least `merged_min` rows lie behind the NEXT super-panel the update is one
     merged launch over the whole trailing matrix (next block column first, t rows); below that the block column is a gemm
-    of its own on the look-ahead stream and the launch covers the rest, t2 rows.  merged_min=None: the round-1 schedule."""
+    of its own on the look-ahead stream and the launch covers the rest, t2 rows.  Once at most `tail_rows` rows trail, one
+    last update covers them all and the rest is factored as a single panel (no further gemm launches).
+    merged_min=None, tail_rows=0: the round-1 schedule."""
     pn = (n + 127) // 128 * 128
+    if pn <= tail_rows:
+        return []
 
     def width(c0):
         left = pn - c0
@@ -146,6 +150,9 @@ def syrk_schedule_launches(n, nb=NB, panels=2, super_min=14336, merged_min=12288
         if t <= 0:
             return out
         r1 = r0 + wc
+        if t <= tail_rows and t % 128 == 0:
+            out.append((t, wc))
+            return out
         w1 = width(r1)
         t2 = t - w1
         if merged_min is not None and t2 > 0 and t2 >= merged_min and w1 % 128 == 0:
@@ -464,6 +471,9 @@ def main():
         }
         if stages is not None:
             out['stages_ms_one_pass'] = stages
+            # stage-level rates of that one pass: every launch of the stage, both streams, against its algorithmic flops
+            out['stage_tflops_one_pass'] = {'potrf': n**3 / 3.0 / (stages['potrf'] * 1e-3) / 1e12,
+                                            'predict_var': float(n) * n * m / (stages['predict_var'] * 1e-3) / 1e12}
             out['predict_mean'] = {'pairs_per_s': timed_pairs / (timed[5][0] * 1e-3) if timed[5][0] > 0 else None,
                                    'ms_per_step': timed[5][0] / args.steps}
         if world == 1 and not args.no_cpu_baseline:

@@ -687,9 +687,20 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     unsigned sync_target = 0;          // tiles counted so far in this factorisation: the word only grows until the next reset
     bool merged_prev = false;          // did the previous step take the merged form (the second stream then owes no event wait)
     if (lookahead && merged_on) MGPI_HIP_TRY(hipMemsetAsync(d_sync, 0, sizeof(unsigned), main_stream));
+    // The TAIL.  Once few rows trail, a panel step (~31 us) is shorter than what surrounds it: the next panel's column update
+    // alone takes 70 - 125 us however small it is (one tile is 32 dependent stages of contraction 16), so the last eight
+    // panels of any factorisation cost ~3.9 ms where their 64 steps need 2.5 (rocprofv3 timeline at N = 8192).  Below
+    // MGPI_TAIL_ROWS trailing rows the rest of the matrix is therefore factored as ONE panel, the way the batched
+    // log-likelihood does it: no column updates, no trailing gemms - the update-role workgroups of every step apply its 64
+    // columns to everything right of them (64 x 64 x 64 tiles from L2, hidden beside the step's own chain).
+    // Measured (potrf, ms; MGPI_TAIL_ROWS = 0 / 2048 / 4096): N=2048 1.28 / 1.13 / 1.12, N=4096 2.74 / 2.55 / 2.56, N=8192 7.53 / 7.36 / 7.41,
+    // N=13824 21.0 / 20.8 / 20.7 - a step costs 35 - 40 us in that form, so the gain is what the column updates cost.
+    static const int64_t tail_rows = getenv("MGPI_TAIL_ROWS") ? atoll(getenv("MGPI_TAIL_ROWS")) : 2048;
     int64_t wc = super_width(0);
+    if (pn <= tail_rows) wc = pn;                                // small matrices: one panel from the start
     mgpi_prof_begin(ctx, 1);
-    MGPI_TRY(factor_super(0, wc, false));
+    if (wc == pn && pn <= tail_rows) MGPI_TRY(factor_panel(0, pn));
+    else MGPI_TRY(factor_super(0, wc, false));
     mgpi_prof_end(ctx, 1);
     if (lookahead) MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
     bool panel_on_side = false;                                  // is the current super-panel the product of stream2?
@@ -698,6 +709,20 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
         const int64_t t = pn - r0 - w;                        // trailing size
         if (t <= 0) break;
         const int64_t r1 = r0 + w;
+        if (t <= tail_rows && t % 128 == 0) {
+            // the whole trailing matrix in one update, then one panel of t columns, everything on the main stream
+            if (lookahead && panel_on_side) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
+            panel_on_side = false;
+            const double* Pt = A + r1 * lda + r0;
+            mgpi_prof_begin(ctx, 0);
+            MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 1, t, t, w, Pt, lda, Pt, lda, A + r1 * lda + r1, lda));
+            mgpi_prof_end(ctx, 0);
+            mgpi_prof_flops(ctx, 0, (double)t * ((double)t + 1.0) * (double)w);
+            mgpi_prof_begin(ctx, 1);
+            MGPI_TRY(factor_panel(r1, t));
+            mgpi_prof_end(ctx, 1);
+            break;
+        }
         const int64_t w1 = super_width(r1);                  // super-panel k+1
         const double* P = A + r1 * lda + r0;                  // rows r1.., the w columns of super-panel k
         const int64_t t2 = t - w1;

@@ -13,10 +13,10 @@ def test_flop_formulas_match_survey_8d():
     assert bench.syrk_launch_flops(32768) < t and bench.syrk_launch_flops(32768) > 0.93 * t
     # the shipped schedule (two panels per update above 14336 trailing rows) moves a little more of it into the column
     # updates; profiles/r01_c3_bench.json records the library's own count of exactly this number
-    assert bench.syrk_schedule_flops(32768, merged_min=None) == 10320634183680.0
-    assert bench.syrk_schedule_flops(32768, panels=1, merged_min=None) == bench.syrk_launch_flops(32768)
+    assert bench.syrk_schedule_flops(32768, merged_min=None, tail_rows=0) == 10320634183680.0
+    assert bench.syrk_schedule_flops(32768, panels=1, merged_min=None, tail_rows=0) == bench.syrk_launch_flops(32768)
     # the merged trailing update folds the next block column into the launch while >= 12288 rows trail: more of the total
-    assert bench.syrk_schedule_flops(32768, merged_min=None) < bench.syrk_schedule_flops(32768) < t
+    assert bench.syrk_schedule_flops(32768, merged_min=None, tail_rows=0) < bench.syrk_schedule_flops(32768) < t
     n, m = 32768, 4096
     assert bench.step_flops(n, m) == n**3 / 3.0 + 2.0 * n * n + float(n) * n * m + 2.0 * m * n
 
