@@ -32,6 +32,10 @@ __global__ __launch_bounds__(256) void load_kernel(int iters, const double* in, 
     double a0 = in[threadIdx.x], a1 = in[256 + threadIdx.x], b0 = a1 + 1, b1 = a0 - 1, b2 = a0 + a1, b3 = a0 - a1;
     const double2* lds2 = reinterpret_cast<const double2*>(fill) + threadIdx.x;
     double2 acc_l = {0, 0};
+    unsigned iacc = threadIdx.x;
+    double ind[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ind[q] = 0.0;
     for (int it = 0; it < iters; ++it) {
         if (LDS_MODE == 1 && (it & 3) == 0) {             // the real kernel's shape: 8 x 1 KB reads in one burst per 32 MFMAs
 #pragma unroll
@@ -44,6 +48,21 @@ __global__ __launch_bounds__(256) void load_kernel(int iters, const double* in, 
         if (LDS_MODE == 3 && (it & 3) == 0) {             // VALU only: 16 fp64 adds per 32 MFMAs, no LDS
 #pragma unroll
             for (int q = 0; q < 8; ++q) { acc_l.x += a0; acc_l.y += a1; }
+        }
+        if (LDS_MODE == 6 && (it & 3) == 0) {             // scalar only: 16 s_nop
+#pragma unroll
+            for (int q = 0; q < 16; ++q) asm volatile("s_nop 0");
+        }
+        if (LDS_MODE == 7 && (it & 3) == 0) {             // 16 dependent 32-bit integer adds
+#pragma unroll
+            for (int q = 0; q < 16; ++q) asm volatile("v_add_u32 %0, %0, %0" : "+v"(iacc));
+        }
+        if (LDS_MODE == 8 && (it & 3) == 0) {             // 16 INDEPENDENT fp64 adds (sixteen accumulators)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) ind[q] += a0;
+        }
+        if (LDS_MODE == 9) {                              // ONE fp64 add after every 8 MFMAs
+            acc_l.x += a0;
         }
         if (LDS_MODE == 4 && (it & 3) == 0) {             // LDS only: the reads land in registers nobody adds up
 #pragma unroll
@@ -63,7 +82,7 @@ __global__ __launch_bounds__(256) void load_kernel(int iters, const double* in, 
         }
     }
     double4_t s4 = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
-    if (s4[0] + s4[1] + s4[2] + s4[3] + m.x + m.y + fill[threadIdx.x ^ 1] + acc_l.x + acc_l.y == 1.2345) out[0] = s4[0];
+    if (s4[0] + s4[1] + s4[2] + s4[3] + m.x + m.y + fill[threadIdx.x ^ 1] + acc_l.x + acc_l.y + iacc + ind[0] + ind[5] + ind[15] == 1.2345) out[0] = s4[0];
 }
 
 template <int MODE, bool PRIO>
@@ -83,6 +102,8 @@ __global__ __launch_bounds__(256) void chain_kernel(int n, const double* in, dou
         if (MODE == 2) p = ring[p];
         if (MODE == 3) MFMA_V(acc, a, b);
         if (MODE == 4) p = chase[p];
+        if (MODE == 5) a = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, a, 0, 0, 0);      // dependent through BOTH the A operand and the accumulator
+        if (MODE == 6) a = __builtin_amdgcn_mfma_f64_4x4x4f64(b, b, a, 0, 0, 0);      // dependent through the accumulator only
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if ((threadIdx.x & 63) == 0) { clk[threadIdx.x >> 6] = t1 - t0; clk[4 + (threadIdx.x >> 6)] = where_am_i(); }
@@ -125,11 +146,17 @@ int main() {
     double2* mem;
     CHECK(hipMalloc(&mem, mem_n * 16));
     CHECK(hipMemset(mem, 0, mem_n * 16));
-    const char* names[5] = {"dependent v_fma_f64", "dependent v_add_u32", "dependent ds_read", "dependent v_mfma_f64_16x16x4", "dependent global load (64 MB table)"};
-    for (int load = 0; load < 10; ++load) {                 // 0: idle chip; 1, 2: one / two MFMA waves per SIMD; 3, 4: the same + streaming loads; 5, 6: two waves + LDS reads (burst / spread)
+    const char* names[7] = {"dependent v_fma_f64", "dependent v_add_u32", "dependent ds_read", "dependent v_mfma_f64_16x16x4", "dependent global load (64 MB table)",
+                            "dependent v_mfma_f64_4x4x4 (A and C)", "dependent v_mfma_f64_4x4x4 (C only)"};
+    for (int load = 0; load < 14; ++load) {
+        if (load == 1 || load == 3 || load == 4 || load == 6 || (load >= 8 && load != 10)) continue;                 // 0: idle chip; 1, 2: one / two MFMA waves per SIMD; 3, 4: the same + streaming loads; 5, 6: two waves + LDS reads (burst / spread)
         const int waves = load == 0 ? 0 : (load >= 5 ? 2 : (load - 1) % 2 + 1);
         if (load == 7) hipLaunchKernelGGL(load_kernel<3>, dim3(512), dim3(256), 0, sa, 400000, din, dout, (const double2*)nullptr, mem_n - 1);
         if (load == 8) hipLaunchKernelGGL(load_kernel<4>, dim3(512), dim3(256), 0, sa, 400000, din, dout, (const double2*)nullptr, mem_n - 1);
+        if (load == 10) hipLaunchKernelGGL(load_kernel<6>, dim3(512), dim3(256), 0, sa, 400000, din, dout, (const double2*)nullptr, mem_n - 1);
+        if (load == 11) hipLaunchKernelGGL(load_kernel<7>, dim3(512), dim3(256), 0, sa, 400000, din, dout, (const double2*)nullptr, mem_n - 1);
+        if (load == 12) hipLaunchKernelGGL(load_kernel<8>, dim3(512), dim3(256), 0, sa, 400000, din, dout, (const double2*)nullptr, mem_n - 1);
+        if (load == 13) hipLaunchKernelGGL(load_kernel<9>, dim3(512), dim3(256), 0, sa, 400000, din, dout, (const double2*)nullptr, mem_n - 1);
         if (load == 9) hipLaunchKernelGGL(load_kernel<5>, dim3(512), dim3(256), 0, sa, 400000, din, dout, (const double2*)nullptr, mem_n - 1);
         const bool with_mem = load == 3 || load == 4;
         if (load) {
@@ -140,14 +167,16 @@ int main() {
             hipLaunchKernelGGL((chain_kernel<0, false>), dim3(1), dim3(256), 0, sb, 100, din, dout, dclk, chase);   // let the load start
             CHECK(hipStreamSynchronize(sb));
         }
-        double r[5][2];
+        double r[7][2];
         r[0][0] = chain<0, false>(sb, n, din, dout, dclk, chase); r[0][1] = chain<0, true>(sb, n, din, dout, dclk, chase);
         r[1][0] = chain<1, false>(sb, n, din, dout, dclk, chase); r[1][1] = chain<1, true>(sb, n, din, dout, dclk, chase);
         r[2][0] = chain<2, false>(sb, n, din, dout, dclk, chase); r[2][1] = chain<2, true>(sb, n, din, dout, dclk, chase);
         r[3][0] = chain<3, false>(sb, n, din, dout, dclk, chase); r[3][1] = chain<3, true>(sb, n, din, dout, dclk, chase);
         r[4][0] = chain<4, false>(sb, n, din, dout, dclk, chase); r[4][1] = chain<4, true>(sb, n, din, dout, dclk, chase);
+        r[5][0] = chain<5, false>(sb, n, din, dout, dclk, chase); r[5][1] = chain<5, true>(sb, n, din, dout, dclk, chase);
+        r[6][0] = chain<6, false>(sb, n, din, dout, dclk, chase); r[6][1] = chain<6, true>(sb, n, din, dout, dclk, chase);
         hipError_t q = hipStreamQuery(sa);
-        printf("load: %d MFMA wave(s) per SIMD%s%s\n", waves, with_mem ? " + 16 B per lane per 8 MFMAs streamed from a 4 GB buffer" : load == 5 ? " + 8 ds_read_b128 in a burst per 32 MFMAs" : load == 6 ? " + 2 ds_read_b128 per 8 MFMAs" : load == 7 ? " + 16 v_add_f64 per 32 MFMAs, no LDS" : load == 8 ? " + 8 ds_read_b128 per 32 MFMAs, results unused" : load == 9 ? " + burst of 8 reads and adds, then s_sleep 1" : "",
+        printf("load: %d MFMA wave(s) per SIMD%s%s\n", waves, with_mem ? " + 16 B per lane per 8 MFMAs streamed from a 4 GB buffer" : load == 5 ? " + 8 ds_read_b128 in a burst per 32 MFMAs" : load == 6 ? " + 2 ds_read_b128 per 8 MFMAs" : load == 7 ? " + 16 v_add_f64 per 32 MFMAs, no LDS" : load == 8 ? " + 8 ds_read_b128 per 32 MFMAs, results unused" : load == 9 ? " + burst of 8 reads and adds, then s_sleep 1" : load == 10 ? " + 16 s_nop per 32 MFMAs" : load == 11 ? " + 16 dependent v_add_u32 per 32 MFMAs" : load == 12 ? " + 16 independent v_add_f64 per 32 MFMAs" : load == 13 ? " + one v_add_f64 per 8 MFMAs" : "",
                load ? (q == hipErrorNotReady ? " (still running: the chains ran beside it)" : " (ALREADY FINISHED)") : "");
         if (load) {
             std::vector<unsigned> lw(4096);
@@ -160,7 +189,7 @@ int main() {
             printf("   the last chain's wave 0 ran on xcc %u se %u sh %u cu %u simd %u: %d load waves on that CU, %d on that SIMD\n", g_chain_where >> 16,
                    (g_chain_where >> 13) & 7, (g_chain_where >> 12) & 1, (g_chain_where >> 8) & 15, (g_chain_where >> 4) & 3, same_cu, same_simd);
         }
-        for (int m = 0; m < 5; ++m) printf("   %-38s %7.1f cycles per op, %7.1f with s_setprio 3\n", names[m], r[m][0], r[m][1]);
+        for (int m = 0; m < 7; ++m) printf("   %-38s %7.1f cycles per op, %7.1f with s_setprio 3\n", names[m], r[m][0], r[m][1]);
         CHECK(hipStreamSynchronize(sa));
     }
     return 0;
