@@ -811,9 +811,18 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
     MGPI_TRY(potrf_enqueue(ctx, K, 0, 0));
     int info = 0;
     double ld = 0.0;
-    MGPI_HIP_TRY(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    MGPI_HIP_TRY(hipMemcpyAsync(&ld, ctx->d_scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_pinned) {
+        char* land = (char*)ctx->h_pinned;
+        MGPI_HIP_TRY(hipMemcpyAsync(land, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        MGPI_HIP_TRY(hipMemcpyAsync(land + 8, ctx->d_scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        memcpy(&info, land, sizeof(int));
+        memcpy(&ld, land + 8, sizeof(double));
+    } else {
+        MGPI_HIP_TRY(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        MGPI_HIP_TRY(hipMemcpyAsync(&ld, ctx->d_scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
     if (info < 0) {
         K->factored = 0;
         mgpi_set_error("mgpi_potrf_dev: the trailing update's progress counter was not reached (internal error)");
@@ -999,11 +1008,17 @@ extern "C" int mgpi_loglikelihood_batch(mgpi_ctx* ctx, const mgpi_mat* X, const 
     hipLaunchKernelGGL(ll_finish_kernel, dim3((unsigned)batch), dim3(256), 0, ctx->stream, A, lda, strideA, n, pn, S, I, O);
     MGPI_HIP_TRY(hipGetLastError());
     // values and status words sit next to each other: one read-back
-    std::vector<char> back(bytesO + (size_t)batch * sizeof(int));
-    MGPI_HIP_TRY(hipMemcpyAsync(back.data(), O, back.size(), hipMemcpyDeviceToHost, ctx->stream));
+    const size_t back_bytes = bytesO + (size_t)batch * sizeof(int);
+    std::vector<char> pageable;
+    char* back = (char*)ctx->h_pinned;
+    if (back == nullptr || back_bytes > MGPI_PINNED_BYTES) {
+        pageable.resize(back_bytes);
+        back = pageable.data();
+    }
+    MGPI_HIP_TRY(hipMemcpyAsync(back, O, back_bytes, hipMemcpyDeviceToHost, ctx->stream));
     MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    memcpy(out, back.data(), (size_t)batch * sizeof(double));
-    if (info) memcpy(info, back.data() + bytesO, (size_t)batch * sizeof(int));
+    memcpy(out, back, (size_t)batch * sizeof(double));
+    if (info) memcpy(info, back + bytesO, (size_t)batch * sizeof(int));
     return 0;
 }
 

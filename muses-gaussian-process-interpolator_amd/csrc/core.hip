@@ -66,6 +66,10 @@ extern "C" int mgpi_ctx_create(int device_id, int nb, mgpi_ctx** out) {
     MGPI_HIP_TRY(hipMalloc((void**)&c->d_info, 64));
     MGPI_HIP_TRY(hipMalloc((void**)&c->d_scal, 8192 * sizeof(double)));
     MGPI_HIP_TRY(hipMemset(c->d_info, 0, 64));
+    if (hipHostMalloc(&c->h_pinned, MGPI_PINNED_BYTES, hipHostMallocDefault) != hipSuccess) {   // optional: pageable read-backs still work
+        (void)hipGetLastError();
+        c->h_pinned = nullptr;
+    }
     c->pool = new mgpi_pool();
     {
         size_t free_b = 0, total_b = 0;
@@ -152,6 +156,7 @@ extern "C" int mgpi_ctx_destroy(mgpi_ctx* ctx) {
     if (ctx->d_diag) (void)hipFree(ctx->d_diag);
     (void)hipFree(ctx->d_info);
     (void)hipFree(ctx->d_scal);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     for (int s = 0; s < MGPI_PROF_SLOTS; ++s) {

@@ -20,6 +20,7 @@ struct mgpi_prof_slot {
 };
 
 #define MGPI_PROF_SLOTS 6
+#define MGPI_PINNED_BYTES (64 * 1024)
 struct mgpi_pool;
 
 struct mgpi_ctx {
@@ -39,6 +40,8 @@ struct mgpi_ctx {
                                   // column update, 4 big update of the multi-rhs forward solve (variance), 5 fused predict mean
     int* d_info;                  // device: first failing pivot (0 = none)
     double* d_scal;               // device scratch, 8192 doubles: [0] logdet, [1] status accumulator, [64, 64 + 64*64 + 64) panel images, [8000] barrier token, [8064] progress counter of the merged trailing update
+    void* h_pinned;               // 64 KB of pinned host memory: small read-backs (status words, log-likelihood values) land here
+                                  // without the staging copy a pageable destination costs (MGPI_PINNED_BYTES)
     double* d_diag;               // diag(K) before factoring (pivot threshold), grown on demand
     int64_t diag_len;
     double* work;                 // device workspace, grown on demand

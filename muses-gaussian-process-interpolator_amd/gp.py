@@ -155,6 +155,7 @@ class Interpolator(HyperParameterSearch):
         self.kernel = kernel
         self.nugget = nugget
         self._context = context
+        self._ll_data = None           # (context, x copy, f copy, X device, f device) of the last loglikelihood data
 
     @property
     def context(self):
@@ -401,6 +402,25 @@ class Interpolator(HyperParameterSearch):
         assert len(f) == len(x), 'source_f has %d entries for %d source points' % (len(f), len(x))
         return _lib.DeviceMatrix.from_host(self.context, x), _lib.DeviceMatrix.from_host(self.context, f)
 
+    _LL_CACHE_BYTES = 64 << 20
+
+    def _resident_if_unchanged(self, source_x, source_f):
+        """the device copies of the previous call's (x, f) when this call's arrays hold the same values - a hyper-parameter
+        search through the reference's own entry point, loglikelihood(source_x, source_f) at changing kernel parameters
+        (interpolators.py:331-343, 382), then uploads its data once.  The comparison is by VALUE against a private host
+        copy (a caller may mutate its arrays in place between calls; NaNs never compare equal and are uploaded again);
+        tables above 64 MB are not kept."""
+        x = _points(source_x)
+        f = _lib.as_f64(source_f).reshape(-1)
+        assert len(f) == len(x), 'source_f has %d entries for %d source points' % (len(f), len(x))
+        c = getattr(self, '_ll_data', None)
+        if (c is not None and c[0] is self.context and c[1].shape == x.shape and c[2].shape == f.shape
+                and np.array_equal(c[1], x) and np.array_equal(c[2], f)):
+            return c[3], c[4]
+        X, F = _lib.DeviceMatrix.from_host(self.context, x), _lib.DeviceMatrix.from_host(self.context, f)
+        self._ll_data = (self.context, x.copy(), f.copy(), X, F) if x.nbytes + f.nbytes <= self._LL_CACHE_BYTES else None
+        return X, F
+
     def loglikelihoods(self, source_x, source_f, kernel_params, resident=None, verbose=False):
         """additive: the log marginal likelihood for EVERY row of kernel_params (kernel parameter vectors in kernel
         order, like Kernel.update(*row)) in one device call - the walkers of sample_kernel, the probes of
@@ -408,7 +428,7 @@ class Interpolator(HyperParameterSearch):
         gets -inf and its failing pivot, the others are unaffected.  The kernel's own parameters are left as they were.
         `resident` = self.resident(source_x, source_f) skips the upload of x and f."""
         rows = np.atleast_2d(np.asarray(kernel_params, dtype=float))
-        X, F = resident if resident is not None else self.resident(source_x, source_f)
+        X, F = resident if resident is not None else self._resident_if_unchanged(source_x, source_f)
         ctx = self.context
         keep = np.array(self.kernel.params, dtype=float)
         try:

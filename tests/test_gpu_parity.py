@@ -443,6 +443,42 @@ def test_loglikelihood_batch_matches_single_calls_and_golden():
         kernel.update(*base)
 
 
+def test_loglikelihood_keeps_unchanged_data_on_the_device_and_sees_every_change():
+    """Interpolator.loglikelihood(x, f) - the reference's entry point, called again and again by a hyper-parameter search
+    (interpolators.py:331-343, 382) - reuses the device copies of x and f while their VALUES are unchanged, and uploads again
+    when a caller mutates an array in place, passes other arrays of the same shape, or changes the shape"""
+    rng = np.random.default_rng(11)
+    x = rng.random((200, 2))
+    f = np.sin(3 * x[:, 0]) + x[:, 1]
+    kernel, nugget = mgpi.SquaredExponentialKernel(1.0, 0.3, 0.4), mgpi.WhiteNoiseKernel(0.05)
+    it = mgpi.Interpolator(kernel, nugget=nugget)
+
+    def ref(xx, ff):
+        return oracle.loglikelihood(oracle_terms_of(kernel), oracle_terms_of(nugget), xx, ff)
+
+    v0 = it.loglikelihood(x, f)
+    held = it._ll_data[3], it._ll_data[4]
+    assert abs(v0 - ref(x, f)) < 1e-10 * abs(v0)
+    assert it.loglikelihood(x.copy(), f.copy()) == v0 and (it._ll_data[3], it._ll_data[4]) == held      # same values: no upload
+    kernel.update(1.2, 0.25, 0.5)                                                                       # new parameters, same data
+    v1 = it.loglikelihood(x, f)
+    assert (it._ll_data[3], it._ll_data[4]) == held and abs(v1 - ref(x, f)) < 1e-10 * abs(v1) and v1 != v0
+    f[17] += 0.5                                                                                        # mutated in place
+    v2 = it.loglikelihood(x, f)
+    assert it._ll_data[4] is not held[1] and abs(v2 - ref(x, f)) < 1e-10 * abs(v2) and v2 != v1
+    x2 = rng.random((200, 2))                                                                           # other points, same shape
+    v3 = it.loglikelihood(x2, f)
+    assert abs(v3 - ref(x2, f)) < 1e-10 * abs(v3)
+    v4 = it.loglikelihood(x2[:150], f[:150])                                                            # other shape
+    assert abs(v4 - ref(x2[:150], f[:150])) < 1e-10 * abs(v4)
+    fn = f.copy()
+    fn[3] = np.nan                                                                                      # NaNs never compare equal
+    it.loglikelihoods(x2, fn, [np.array(kernel.params, dtype=float)])
+    a = it._ll_data[4]
+    it.loglikelihoods(x2, fn, [np.array(kernel.params, dtype=float)])
+    assert it._ll_data[4] is not a
+
+
 def oracle_terms_of(k):
     if k is None:
         return []
