@@ -505,11 +505,11 @@ __global__ __launch_bounds__(256) void logdiag_kernel(const double* __restrict__
 // that runs on the main stream.  hipStreamWaitValue32 does the same without a wave (measured equal: ~1 us from the last
 // increment to the next kernel's start, tools/waitvalue_probe.hip) but a factorisation that uses it never finishes under
 // rocprofv3 --pmc (tools/pmc_hang_probe.sh), so it is not used.  The producer is always submitted before this kernel, and the
-// poll is bounded: after 2^21 sleeps (~6 s) it gives up and flags the factorisation as failed (status -1) instead of hanging.
+// poll is bounded: after 2^23 sleeps (~23 s; the largest trailing update that fits the HBM takes ~1.5 s) it gives up and flags the factorisation as failed (status -1) instead of hanging.
 __global__ void wait_count_kernel(const unsigned* __restrict__ counter, unsigned want, int* __restrict__ info) {
     if (threadIdx.x != 0) return;
     if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) return;      // an earlier wait of this factorisation gave up
-    for (int guard = 0; guard < (1 << 21); ++guard) {
+    for (int guard = 0; guard < (1 << 23); ++guard) {
         if ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) return;
         __builtin_amdgcn_s_sleep(32);
     }
