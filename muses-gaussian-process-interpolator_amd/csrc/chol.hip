@@ -232,6 +232,7 @@ extern "C" int mgpi_debug_read_trace(unsigned long long* host, unsigned* n) {
 #define PT_STAMP(k) do { } while (0)
 #define PT_FLUSH(role) do { } while (0)
 #endif
+template <bool MX>
 __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__ A, int64_t lda, int64_t c0, int has_prev, int nfused,
                                                          int rest_cols, int64_t pivot_base, const double* __restrict__ diag0,
                                                          int* __restrict__ info, double* __restrict__ S, double ptol, int mode,
@@ -305,9 +306,22 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__
         }
     }
     __syncthreads();                                               // the factor's LDS images are complete
-    trsm_acc_rounds<0>::run(acc, s, w, g, c, A + (r0 + 16 * w + c) * lda + c0);
+    if constexpr (MX) {
+        panel_trsm_images(s, tid);
+        trsm_acc_mx<0>::run(acc, s, w, g, c, A + (r0 + 16 * w + c) * lda + c0);
+    } else {
+        trsm_acc_rounds<0>::run(acc, s, w, g, c, A + (r0 + 16 * w + c) * lda + c0);
+    }
     PT_STAMP(3);
     PT_FLUSH(1);
+}
+
+// MGPI_PANEL_MX=0 selects the vector-pipe substitution (developer switch, both forms are tested)
+typedef void (*panel_step_fn)(double*, int64_t, int64_t, int, int, int, int64_t, const double*, int*, double*, double, int, double*, int64_t,
+                              int64_t, int64_t);
+static panel_step_fn panel_step_entry() {
+    static const bool mx = getenv("MGPI_PANEL_MX") ? atoi(getenv("MGPI_PANEL_MX")) != 0 : true;
+    return mx ? panel_step_kernel<true> : panel_step_kernel<false>;
 }
 
 // one step: diagonal block at (c0, c0) of the matrix A (c0 absolute), `rows_below` rows below the block, the panel ends at
@@ -322,13 +336,13 @@ static int launch_panel_step(mgpi_ctx* ctx, double* A, int64_t lda, int64_t c0, 
     for (int tj = 0; tj < rest_cols; ++tj) nrest += nfused - 1 - tj;       // tiles on/below the diagonal, rows >= c0 + 64
     double* F = ctx->d_scal + 64;                                          // 64 x 64 + 64 doubles of the ctx's scalar scratch
     if (!split) {
-        hipLaunchKernelGGL(panel_step_kernel, dim3((unsigned)(nfused + nrest)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused,
+        hipLaunchKernelGGL(panel_step_entry(), dim3((unsigned)(nfused + nrest)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused,
                            rest_cols, pivot_base, diag0, ctx->d_info, S, ctx->pivot_tol, 0, F, (int64_t)0, (int64_t)0, (int64_t)0);
     } else {
-        hipLaunchKernelGGL(panel_step_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused, rest_cols, pivot_base,
+        hipLaunchKernelGGL(panel_step_entry(), dim3(1), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused, rest_cols, pivot_base,
                            diag0, ctx->d_info, S, ctx->pivot_tol, 1, F, (int64_t)0, (int64_t)0, (int64_t)0);
         if (nfused - 1 + nrest > 0)
-            hipLaunchKernelGGL(panel_step_kernel, dim3((unsigned)(nfused - 1 + nrest)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev,
+            hipLaunchKernelGGL(panel_step_entry(), dim3((unsigned)(nfused - 1 + nrest)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev,
                                nfused, rest_cols, pivot_base, diag0, ctx->d_info, S, ctx->pivot_tol, 2, F, (int64_t)0, (int64_t)0, (int64_t)0);
     }
     MGPI_HIP_TRY(hipGetLastError());
@@ -1001,7 +1015,7 @@ extern "C" int mgpi_loglikelihood_batch(mgpi_ctx* ctx, const mgpi_mat* X, const 
         const int rest_cols = has_prev ? (int)((pn - c0 - IB) / IB) : 0;
         int64_t nrest = 0;
         for (int tj = 0; tj < rest_cols; ++tj) nrest += nfused - 1 - tj;
-        hipLaunchKernelGGL(panel_step_kernel, dim3((unsigned)(nfused + nrest), (unsigned)batch), dim3(256), 0, ctx->stream, A, lda, c0,
+        hipLaunchKernelGGL(panel_step_entry(), dim3((unsigned)(nfused + nrest), (unsigned)batch), dim3(256), 0, ctx->stream, A, lda, c0,
                            has_prev, nfused, rest_cols, c0, D0 + c0, I, S + c0 * IB, ctx->pivot_tol, 0, (double*)nullptr, strideA,
                            pn * IB, pn);
     }

@@ -241,6 +241,10 @@ struct __attribute__((aligned(32))) panel_lds {
     double Lt[IB][IB];         // Lt[k][m] = L[m][k] for m >= k (the factor, transposed: B operand of the substitution), 0 above
     double invd[IB];           // 1 / L[k][k]
     double dtol[IB];           // pivot thresholds
+    // matrix-pipe substitution (trsm_acc_mx): per round R = K / 4 the 4 x 4 diagonal block of L as two A-operand images of
+    // v_mfma_f64_4x4x4 - dgA[R][i][k] = (i == k) / L[K+i][K+i],  tA[R][i][k] = (k < i) * -L[K+i][K+k] / L[K+i][K+i]
+    double dgA[IB / 4][4][4];
+    double tA[IB / 4][4][4];
 };
 
 __device__ __forceinline__ panel_double4_t panel_row4(const double (&p)[4]) {
@@ -430,6 +434,59 @@ struct trsm_acc_rounds {
             for (int n = 0; n < 4; ++n)
                 if (n >= QK) acc[n] = PANEL_MFMA(-yg, s.Lt[K + g][16 * n + c], acc[n]);
             trsm_acc_rounds<K + 4>::run(acc, s, w, g, c, outrow);
+        }
+    }
+};
+
+// ---- the same substitution with its dependent arithmetic on the MATRIX pipe ------------------------------------------------
+// Why: beside the trailing update the vector instructions of a panel wave are starved at issue (a dependent v_fma_f64 costs
+// 430 - 490 cycles there instead of 40, tools/dp_contention_probe.hip), its matrix instructions are not (a dependent
+// v_mfma_f64_4x4x4 costs 77 - 80 instead of 44 - 48).  The 4 x 4 forward substitution of a round is therefore written as
+// matrix products.  v_mfma_f64_4x4x4 multiplies, for every group of four rows (c >> 2), A (4 x 4) by B (4 x 4) with
+//     A[i][k] on lane (c = 4 blk + i, g = k),   B[k][j] and D[i][j] on lane (c = 4 blk + j, g = k resp. i)
+// (tools/mfma4_layout_probe.hip), so with lane (c, g) holding a_g(row c) - the round's raw entry of row c in column K + g -
+// as B, a UNIFORM 4 x 4 matrix T as A gives D(c, g) = sum_k T[g][k] a_k(row c): a combination across the four columns of the
+// same row.  Forward substitution  y = Dg (a - Ls y)  (Dg = 1 / diag, Ls = strictly lower part of the 4 x 4 block) is the
+// fixed point of  y <- y0 + T y  with  y0 = Dg a,  T = -Dg Ls, reached exactly after three steps (T is nilpotent): four
+// dependent matrix instructions per round instead of seven dependent vector instructions, the same arithmetic as the
+// substitution with pre-divided multipliers (no explicit inverse anywhere).  The result lands on lane (c, g) as y_g(row c) -
+// what the store and the A operand of the rank-4 update want, no select.
+#define PANEL_MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
+
+// the two operand images of every round from the factor's LDS images (Lt, invd); all 256 threads, then a barrier
+__device__ __forceinline__ void panel_trsm_images(panel_lds& s, int tid) {
+    for (int e = tid; e < (IB / 4) * 16; e += 256) {
+        const int R = e >> 4, i = (e >> 2) & 3, k = e & 3, K = 4 * R;
+        const double inv = s.invd[K + i];
+        s.dgA[R][i][k] = (i == k) ? inv : 0.0;
+        s.tA[R][i][k] = (k < i) ? -s.Lt[K + k][K + i] * inv : 0.0;
+    }
+    __syncthreads();
+}
+
+template <int K>
+struct trsm_acc_mx {
+    static __device__ __forceinline__ void run(panel_double4_t (&acc)[4], panel_lds& s, int w, int g, int c,
+                                               double* __restrict__ outrow /* &X[(row of 16 w + c)][0] */) {
+        constexpr int QK = K / 16, KL = K % 16, R = K / 4;
+        if (c >= KL && c < KL + 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s.zraw[w][g + 4 * r][c - KL] = acc[QK][r];
+        }
+        __asm__ volatile("" ::: "memory");      // same wave writes and reads the strip: keep the order (see trsm_acc_rounds)
+        const double a = s.zraw[w][c][g];
+        const double dg = s.dgA[R][c & 3][g], t = s.tA[R][c & 3][g];
+        const double y0 = PANEL_MFMA4(dg, a, 0.0);
+        double y = PANEL_MFMA4(t, y0, y0);
+        y = PANEL_MFMA4(t, y, y0);
+        y = PANEL_MFMA4(t, y, y0);
+        outrow[K + g] = y;
+        if constexpr (K + 4 < IB) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (n >= QK) acc[n] = PANEL_MFMA(y, -s.Lt[K + g][16 * n + c], acc[n]);
+            __asm__ volatile("" ::: "memory");  // the next round's strip writes stay behind this round's read
+            trsm_acc_mx<K + 4>::run(acc, s, w, g, c, outrow);
         }
     }
 };

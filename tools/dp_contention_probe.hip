@@ -95,6 +95,9 @@ __global__ __launch_bounds__(256) void chain_kernel(int n, const double* in, dou
     __syncthreads();
     int p = threadIdx.x;
     double4_t acc = {0, 0, 0, 0};
+    double ilp[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ilp[q] = a * (q + 1);
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < n; ++i) {
         if (MODE == 0) a = fma(a, b, 1e-9);
@@ -104,7 +107,16 @@ __global__ __launch_bounds__(256) void chain_kernel(int n, const double* in, dou
         if (MODE == 4) p = chase[p];
         if (MODE == 5) a = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, a, 0, 0, 0);      // dependent through BOTH the A operand and the accumulator
         if (MODE == 6) a = __builtin_amdgcn_mfma_f64_4x4x4f64(b, b, a, 0, 0, 0);      // dependent through the accumulator only
+        if (MODE == 7) {                                                                  // EIGHT independent fma chains: issue-bound or latency-bound?
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ilp[q] = fma(ilp[q], b, 1e-9);
+        }
+        if (MODE == 8) {                                                                  // eight independent 4x4x4 MFMA chains
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ilp[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(b, b, ilp[q], 0, 0, 0);
+        }
     }
+    if (MODE == 7 || MODE == 8) a += ilp[0] + ilp[1] + ilp[2] + ilp[3] + ilp[4] + ilp[5] + ilp[6] + ilp[7];
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if ((threadIdx.x & 63) == 0) { clk[threadIdx.x >> 6] = t1 - t0; clk[4 + (threadIdx.x >> 6)] = where_am_i(); }
     if (a + u + p + acc[0] == 1.2345) out[0] = a;
@@ -146,8 +158,9 @@ int main() {
     double2* mem;
     CHECK(hipMalloc(&mem, mem_n * 16));
     CHECK(hipMemset(mem, 0, mem_n * 16));
-    const char* names[7] = {"dependent v_fma_f64", "dependent v_add_u32", "dependent ds_read", "dependent v_mfma_f64_16x16x4", "dependent global load (64 MB table)",
-                            "dependent v_mfma_f64_4x4x4 (A and C)", "dependent v_mfma_f64_4x4x4 (C only)"};
+    const char* names[9] = {"dependent v_fma_f64", "dependent v_add_u32", "dependent ds_read", "dependent v_mfma_f64_16x16x4", "dependent global load (64 MB table)",
+                            "dependent v_mfma_f64_4x4x4 (A and C)", "dependent v_mfma_f64_4x4x4 (C only)", "8 independent v_fma_f64 chains (per 8 ops)",
+                            "8 independent v_mfma_f64_4x4x4 chains (per 8 ops)"};
     for (int load = 0; load < 14; ++load) {
         if (load == 1 || load == 3 || load == 4 || load == 6 || (load >= 8 && load != 10)) continue;                 // 0: idle chip; 1, 2: one / two MFMA waves per SIMD; 3, 4: the same + streaming loads; 5, 6: two waves + LDS reads (burst / spread)
         const int waves = load == 0 ? 0 : (load >= 5 ? 2 : (load - 1) % 2 + 1);
@@ -167,7 +180,7 @@ int main() {
             hipLaunchKernelGGL((chain_kernel<0, false>), dim3(1), dim3(256), 0, sb, 100, din, dout, dclk, chase);   // let the load start
             CHECK(hipStreamSynchronize(sb));
         }
-        double r[7][2];
+        double r[9][2];
         r[0][0] = chain<0, false>(sb, n, din, dout, dclk, chase); r[0][1] = chain<0, true>(sb, n, din, dout, dclk, chase);
         r[1][0] = chain<1, false>(sb, n, din, dout, dclk, chase); r[1][1] = chain<1, true>(sb, n, din, dout, dclk, chase);
         r[2][0] = chain<2, false>(sb, n, din, dout, dclk, chase); r[2][1] = chain<2, true>(sb, n, din, dout, dclk, chase);
@@ -175,6 +188,8 @@ int main() {
         r[4][0] = chain<4, false>(sb, n, din, dout, dclk, chase); r[4][1] = chain<4, true>(sb, n, din, dout, dclk, chase);
         r[5][0] = chain<5, false>(sb, n, din, dout, dclk, chase); r[5][1] = chain<5, true>(sb, n, din, dout, dclk, chase);
         r[6][0] = chain<6, false>(sb, n, din, dout, dclk, chase); r[6][1] = chain<6, true>(sb, n, din, dout, dclk, chase);
+        r[7][0] = chain<7, false>(sb, n, din, dout, dclk, chase); r[7][1] = chain<7, true>(sb, n, din, dout, dclk, chase);
+        r[8][0] = chain<8, false>(sb, n, din, dout, dclk, chase); r[8][1] = chain<8, true>(sb, n, din, dout, dclk, chase);
         hipError_t q = hipStreamQuery(sa);
         printf("load: %d MFMA wave(s) per SIMD%s%s\n", waves, with_mem ? " + 16 B per lane per 8 MFMAs streamed from a 4 GB buffer" : load == 5 ? " + 8 ds_read_b128 in a burst per 32 MFMAs" : load == 6 ? " + 2 ds_read_b128 per 8 MFMAs" : load == 7 ? " + 16 v_add_f64 per 32 MFMAs, no LDS" : load == 8 ? " + 8 ds_read_b128 per 32 MFMAs, results unused" : load == 9 ? " + burst of 8 reads and adds, then s_sleep 1" : load == 10 ? " + 16 s_nop per 32 MFMAs" : load == 11 ? " + 16 dependent v_add_u32 per 32 MFMAs" : load == 12 ? " + 16 independent v_add_f64 per 32 MFMAs" : load == 13 ? " + one v_add_f64 per 8 MFMAs" : "",
                load ? (q == hipErrorNotReady ? " (still running: the chains ran beside it)" : " (ALREADY FINISHED)") : "");
@@ -189,7 +204,7 @@ int main() {
             printf("   the last chain's wave 0 ran on xcc %u se %u sh %u cu %u simd %u: %d load waves on that CU, %d on that SIMD\n", g_chain_where >> 16,
                    (g_chain_where >> 13) & 7, (g_chain_where >> 12) & 1, (g_chain_where >> 8) & 15, (g_chain_where >> 4) & 3, same_cu, same_simd);
         }
-        for (int m = 0; m < 7; ++m) printf("   %-38s %7.1f cycles per op, %7.1f with s_setprio 3\n", names[m], r[m][0], r[m][1]);
+        for (int m = 0; m < 9; ++m) printf("   %-38s %7.1f cycles per op, %7.1f with s_setprio 3\n", names[m], r[m][0], r[m][1]);
         CHECK(hipStreamSynchronize(sa));
     }
     return 0;
