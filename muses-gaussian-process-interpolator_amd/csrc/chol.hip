@@ -232,7 +232,7 @@ extern "C" int mgpi_debug_read_trace(unsigned long long* host, unsigned* n) {
 #define PT_STAMP(k) do { } while (0)
 #define PT_FLUSH(role) do { } while (0)
 #endif
-template <bool MX>
+template <bool MX, bool MXF>
 __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__ A, int64_t lda, int64_t c0, int has_prev, int nfused,
                                                          int rest_cols, int64_t pivot_base, const double* __restrict__ diag0,
                                                          int* __restrict__ info, double* __restrict__ S, double ptol, int mode,
@@ -284,7 +284,12 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__
             panel_gemm_nt(accD, A + (c0 + 16 * w + c) * lda + kk + 2 * g, A + (c0 + c) * lda + kk + 2 * g, lda, 0, w + 1);
         int bad = 0;
         PT_STAMP(1);
-        potf2_acc_rounds<0>::run(accD, s, w, g, c, bad, b == 0 ? S : nullptr);
+        if constexpr (MXF) {
+            panel_mx_state mxs = panel_mx_begin(s, tid, g, c);
+            potf2_acc_mx<0>::run(accD, s, w, g, c, bad, b == 0 ? S : nullptr, mxs);
+        } else {
+            potf2_acc_rounds<0>::run(accD, s, w, g, c, bad, b == 0 ? S : nullptr);
+        }
         PT_STAMP(2);
         if (b == 0) {
             if (tid == 0 && bad != 0) {
@@ -316,12 +321,18 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__
     PT_FLUSH(1);
 }
 
-// MGPI_PANEL_MX=0 selects the vector-pipe substitution (developer switch, both forms are tested)
+// Matrix-pipe forms of the two sweeps (panel_device.h).  The substitution ships in that form (MGPI_PANEL_MX=0 selects the
+// vector-pipe one): 4.9 -> 3.8 us per 64 rows alone, 20 -> 14 us beside the trailing update.  The factorisation in that form
+// (MGPI_PANEL_MX_FACTOR=1) is correct and tested but does not pay yet: 19.7 us alone against 16.4, and the same ~100 us beside
+// the trailing update - the compiler's code for it still holds ~90 vector instructions per round (register copies around the
+// tied accumulator of the small MFMA, selects), and a wave issues in order, so each of them waits like the ones it replaced.
 typedef void (*panel_step_fn)(double*, int64_t, int64_t, int, int, int, int64_t, const double*, int*, double*, double, int, double*, int64_t,
                               int64_t, int64_t);
 static panel_step_fn panel_step_entry() {
     static const bool mx = getenv("MGPI_PANEL_MX") ? atoi(getenv("MGPI_PANEL_MX")) != 0 : true;
-    return mx ? panel_step_kernel<true> : panel_step_kernel<false>;
+    static const bool mxf = getenv("MGPI_PANEL_MX_FACTOR") ? atoi(getenv("MGPI_PANEL_MX_FACTOR")) != 0 : false;
+    if (mxf) return mx ? panel_step_kernel<true, true> : panel_step_kernel<false, true>;
+    return mx ? panel_step_kernel<true, false> : panel_step_kernel<false, false>;
 }
 
 // one step: diagonal block at (c0, c0) of the matrix A (c0 absolute), `rows_below` rows below the block, the panel ends at

@@ -245,6 +245,13 @@ struct __attribute__((aligned(32))) panel_lds {
     // v_mfma_f64_4x4x4 - dgA[R][i][k] = (i == k) / L[K+i][K+i],  tA[R][i][k] = (k < i) * -L[K+i][K+k] / L[K+i][K+i]
     double dgA[IB / 4][4][4];
     double tA[IB / 4][4][4];
+    // matrix-pipe factorisation (potf2_acc_mx): a zero region the size of raw, and per wave the round's multipliers, negated
+    // reciprocals and pivots as A-operand images / plain vectors; the pivots of all rounds for the check at the end
+    double zeros[2][IB][4];
+    double mA[4][4][4];
+    double rdA[4][4][4];
+    double dsel[4][4];
+    double dall[IB];
 };
 
 __device__ __forceinline__ panel_double4_t panel_row4(const double (&p)[4]) {
@@ -490,6 +497,125 @@ struct trsm_acc_mx {
         }
     }
 };
+
+// ---- 64 x 64 Cholesky with the pivot recurrence and the row solves on the MATRIX pipe ---------------------------------------
+// Same rounds, same LDS exchange and barrier, same rank-4 update as potf2_acc_rounds; what moves is every dependent vector
+// instruction of a round except four reciprocal seeds.  The recurrence of the 4 x 4 pivot block is arithmetic on wave-uniform
+// scalars; a scalar s is carried as the matrix s I_4 of every four-row group - value on the lanes with (c & 3) == g, zero on
+// the others, the same lanes in the A, B and D layouts of v_mfma_f64_4x4x4 - so a product / fused multiply-add of two such
+// scalars is ONE matrix instruction.  Signs are arranged so that nothing is ever negated: the reciprocal is carried as
+// nrd = -1 / d (seed v_rcp_f64 of -d on the diagonal lanes only, one Newton step  nx <- nx + nx (1 + d nx)), the multipliers as
+// nm = p * nrd = -m, which is what the recurrence  d' = p' + nm p  and the row solves want.
+//   * pivot-block entries arrive as s I_4 straight from LDS: the diagonal lanes read the entry, the others read a zero region
+//     at the same offsets (per-lane base pointer, compile-time offsets);
+//   * lane 0 of every wave drops the six multipliers, the four reciprocals and the four pivots into small per-wave LDS images
+//     in A-operand layout; every lane then reads ITS entry of T = -Ms (strictly lower multipliers) and of diag(nrd);
+//   * row solve  M w = a  as the fixed point of  w <- a + T w  (exact after three steps), own rows and the rows that face the
+//     wave's tile columns alike; B operand of the update  nvb = diag(nrd) w, so  acc += w nvb^T  (no negation);
+//   * rows above a column's diagonal produce garbage instead of zeros in w - it only ever reaches accumulator entries that are
+//     dead (finished rows / finished columns); the STORED entries are masked as before;
+//   * the pivots are checked against their thresholds once, after the last round (wave 0, one ballot).
+struct panel_mx_state {
+    const double* pb;      // this lane's base for pivot-block reads: &raw[0][0][0] on the diagonal lanes, the zero region elsewhere
+    double one;            // I_4: 1 on the diagonal lanes
+    double ns;             // the seed register: written on the diagonal lanes only, zero elsewhere for ever
+    bool diag;
+};
+
+template <int K>
+struct potf2_acc_mx {
+    static __device__ __forceinline__ void run(panel_double4_t (&acc)[4], panel_lds& s, int w, int g, int c, int& bad,
+                                               double* __restrict__ S, panel_mx_state& st) {
+        constexpr int QK = K / 16, KL = K % 16, B = (K / 4) & 1;
+        if (w >= QK && c >= KL && c < KL + 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s.raw[B][16 * w + g + 4 * r][c - KL] = acc[QK][r];
+        }
+        __syncthreads();
+        // pivot block as s I_4 (lower part), raw[B][K + i][j] at offset ((B * IB + K + i) * 4 + j)
+        const double* pb = st.pb + (B * IB + K) * 4;
+        const double P00 = pb[0], P10 = pb[4], P11 = pb[5], P20 = pb[8], P21 = pb[9], P22 = pb[10];
+        const double P30 = pb[12], P31 = pb[13], P32 = pb[14], P33 = pb[15];
+        const int row = 16 * w + c;
+        const double a = s.raw[B][row][g];                       // own row, component g
+        auto nrecip = [&](double d) -> double {                 // -1 / d on the diagonal lanes (0 elsewhere)
+            double ns = st.ns;
+            if (st.diag) ns = __builtin_amdgcn_rcp(-d);
+            const double e = PANEL_MFMA4(d, ns, st.one);         // 1 + d ns
+            return PANEL_MFMA4(e, ns, ns);                       // ns + ns e
+        };
+        const double d0 = P00;
+        const double nrd0 = nrecip(d0);
+        const double nm10 = PANEL_MFMA4(P10, nrd0, 0.0), nm20 = PANEL_MFMA4(P20, nrd0, 0.0), nm30 = PANEL_MFMA4(P30, nrd0, 0.0);
+        const double d1 = PANEL_MFMA4(nm10, P10, P11);
+        const double q21 = PANEL_MFMA4(nm20, P10, P21), q31 = PANEL_MFMA4(nm30, P10, P31);
+        const double u22 = PANEL_MFMA4(nm20, P20, P22), u32 = PANEL_MFMA4(nm30, P20, P32), u33 = PANEL_MFMA4(nm30, P30, P33);
+        const double nrd1 = nrecip(d1);
+        const double nm21 = PANEL_MFMA4(q21, nrd1, 0.0), nm31 = PANEL_MFMA4(q31, nrd1, 0.0);
+        const double d2 = PANEL_MFMA4(nm21, q21, u22);
+        const double q32 = PANEL_MFMA4(nm31, q21, u32);
+        const double v33 = PANEL_MFMA4(nm31, q31, u33);
+        const double nrd2 = nrecip(d2);
+        const double nm32 = PANEL_MFMA4(q32, nrd2, 0.0);
+        const double d3 = PANEL_MFMA4(nm32, q32, v33);
+        const double nrd3 = nrecip(d3);
+        // the images: lane 0 of the wave holds every one of these scalars (it is a diagonal lane)
+        if ((threadIdx.x & 63) == 0) {
+            s.mA[w][1][0] = nm10; s.mA[w][2][0] = nm20; s.mA[w][2][1] = nm21;
+            s.mA[w][3][0] = nm30; s.mA[w][3][1] = nm31; s.mA[w][3][2] = nm32;
+            s.rdA[w][0][0] = nrd0; s.rdA[w][1][1] = nrd1; s.rdA[w][2][2] = nrd2; s.rdA[w][3][3] = nrd3;
+            s.dsel[w][0] = d0; s.dsel[w][1] = d1; s.dsel[w][2] = d2; s.dsel[w][3] = d3;
+            if (w == 0) { s.dall[K] = d0; s.dall[K + 1] = d1; s.dall[K + 2] = d2; s.dall[K + 3] = d3; }
+        }
+        __asm__ volatile("" ::: "memory");                       // the wave reads back what its lane 0 has just written (LDS is in order)
+        const double tA = s.mA[w][c & 3][g], rA = s.rdA[w][c & 3][g];
+        const double dg = s.dsel[w][g];
+        auto solve = [&](double b) -> double {                   // M w = b for the four columns of one row, component g on lane (c, g)
+            double v = PANEL_MFMA4(tA, b, b);
+            v = PANEL_MFMA4(tA, v, b);
+            return PANEL_MFMA4(tA, v, b);
+        };
+        const double wa = solve(a);
+        if (w >= QK) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if (n >= QK && n <= w) {
+                    const double wn = (n == w) ? wa : solve(s.raw[B][16 * n + c][g]);
+                    const double nvb = PANEL_MFMA4(rA, wn, 0.0);                       // -w / d, component g
+                    acc[n] = PANEL_MFMA(wa, nvb, acc[n]);
+                }
+            }
+        }
+        // finished entries of columns K..K+3: zeros above the diagonal and for the waves above the block
+        const double ig = rsq_refined(dg);
+        const double x = (w >= QK && row >= K + g) ? wa * ig : 0.0;
+        if (w >= QK) s.Lt[K + g][row] = x;
+        if (row == K + g) s.invd[K + g] = ig;
+        if (S != nullptr) S[(int64_t)row * IB + K + g] = x;
+        if constexpr (K + 4 < IB) {
+            potf2_acc_mx<K + 4>::run(acc, s, w, g, c, bad, S, st);
+        } else {
+            if (w == 0) {                                        // the pivots against their thresholds, once
+                const int l = threadIdx.x & 63;
+                const bool fail = !(s.dall[l] > s.dtol[l]);
+                const unsigned long long m = __ballot(fail);
+                bad = m ? (int)__ffsll((long long)m) : 0;
+            }
+        }
+    }
+};
+
+// zero region, images and per-lane state of the matrix-pipe factorisation; all 256 threads, before the first round
+__device__ __forceinline__ panel_mx_state panel_mx_begin(panel_lds& s, int tid, int g, int c) {
+    for (int e = tid; e < 2 * IB * 4; e += 256) (&s.zeros[0][0][0])[e] = 0.0;
+    for (int e = tid; e < 4 * 16; e += 256) { (&s.mA[0][0][0])[e] = 0.0; (&s.rdA[0][0][0])[e] = 0.0; }
+    panel_mx_state st;
+    st.diag = (c & 3) == g;
+    st.pb = st.diag ? &s.raw[0][0][0] : &s.zeros[0][0][0];
+    st.one = st.diag ? 1.0 : 0.0;
+    st.ns = 0.0;
+    return st;
+}
 
 // load / store one wave's tile row of a 64 x 64 block: acc[n][r] <-> X[(16 w + g + 4 r) * ld + 16 n + c]
 __device__ __forceinline__ void panel_load(panel_double4_t (&acc)[4], const double* __restrict__ X, int64_t ld, int w, int g, int c,

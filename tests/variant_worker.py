@@ -39,6 +39,24 @@ for (m, n, k) in [(256, 384, 512), (640, 640, 48), (128, 128, 16)]:
                 blk = (slice(128 * ti, 128 * ti + 128), slice(128 * tj, 128 * tj + 128))
                 assert np.array_equal(got[blk], want[blk] if tj <= ti else C0[blk]), ('lower', ti, tj)
 
+# the factor itself against LAPACK, and the index of the first failing pivot (whatever form the 64 x 64 sweeps take)
+for nn in (65, 200, 513):
+    xx = rng.random((nn, 2))
+    Kk = mgpi.Interpolator._x2cov(xx, xx, mgpi.SquaredExponentialKernel(1.0, 0.2, 0.3) + mgpi.WhiteNoiseKernel(0.05))
+    dK = dev(Kk)
+    _lib.check(lib.mgpi_potrf_dev(h, dK.handle, None))
+    Lg, Lr = np.tril(dK.to_host()), np.linalg.cholesky(Kk)
+    assert np.max(np.abs(Lg - Lr)) / np.max(np.abs(Lr)) < 1e-11, ('potrf vs lapack', nn)
+    assert np.max(np.abs(Lg @ Lg.T - Kk)) / np.max(np.abs(Kk)) < 1e-14, ('L L^T', nn)
+Kb = np.eye(300)
+Kb[150, 150] = -1.0
+dKb = dev(Kb)
+try:
+    _lib.check(lib.mgpi_potrf_dev(h, dKb.handle, None))
+    raise SystemExit('an indefinite matrix was accepted')
+except mgpi.NotPositiveDefinite as err:
+    assert err.pivot == 151, err.pivot
+
 n = 1700
 x = rng.random((n, 3))
 f = np.sin(3 * x[:, 0]) + x[:, 1] * x[:, 2]
