@@ -249,7 +249,10 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__
     S += (int64_t)blockIdx.y * strideS;
     diag0 += (int64_t)blockIdx.y * strideD;
     info += blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    // the wave index in a scalar register: branches on it become scalar branches instead of EXEC-masked regions whose merges
+    // copy every accumulator (60 v_mov_b64 per round - vector instructions the starved issue stage pays for one by one)
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t cp = c0 - IB, c1 = c0 + IB;
     panel_double4_t acc[4];
     const int first_fused = (mode == 2) ? 1 : 0;                 // mode 2 has no workgroup for the diagonal block's rows
@@ -1615,7 +1618,10 @@ __global__ __launch_bounds__(256, 2) void trsm_right_step_kernel(double* __restr
                                                                  int rest_cols) {
     __shared__ panel_lds s;
     MGPI_CHAIN_PRIO();
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    // the wave index in a scalar register: branches on it become scalar branches instead of EXEC-masked regions whose merges
+    // copy every accumulator (60 v_mov_b64 per round - vector instructions the starved issue stage pays for one by one)
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t cp = c0 - IB, c1 = c0 + IB;
     panel_double4_t acc[4];
     if ((int)blockIdx.x >= nrowblk) {

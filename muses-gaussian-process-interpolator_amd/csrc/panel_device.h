@@ -368,19 +368,23 @@ struct potf2_acc_rounds {
         long long st2a = 0, st2b = 0;
         if (K == 32) { asm volatile("" :: "v"(wa)); st2a = clock64(); }
 #endif
-        if (w >= QK) {
+        // The update itself is UNCONDITIONAL for the tile columns n >= QK (compile time): where it does not apply - tile
+        // columns right of the wave's own (upper triangle), waves above the block - the B operand is zero (resp. the rows are
+        // finished and their accumulators dead).  With the matrix instruction inside the run-time conditions every merge point
+        // copied the accumulators it had touched: ~40 v_mov_b64 per round, vector instructions a starved issue stage pays for.
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                if (n >= QK && n <= w) {
-                    double vb;
+        for (int n = 0; n < 4; ++n) {
+            if (n >= QK) {
+                double vb = 0.0;
+                if (w >= QK && n <= w) {
                     if (n == w) {
                         vb = wa * rdg;
                     } else {
                         const panel_double4_t br = panel_row4(s.raw[B][16 * n + c]);
                         vb = solve(br, 16 * n + c) * rdg;
                     }
-                    acc[n] = PANEL_MFMA(-wa, vb, acc[n]);
                 }
+                acc[n] = PANEL_MFMA(-wa, vb, acc[n]);
             }
         }
 #ifdef PANEL_STAMPS
@@ -576,14 +580,15 @@ struct potf2_acc_mx {
             return PANEL_MFMA4(tA, v, b);
         };
         const double wa = solve(a);
-        if (w >= QK) {
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                if (n >= QK && n <= w) {
+        for (int n = 0; n < 4; ++n) {
+            if (n >= QK) {                                       // unconditional matrix instruction, zero B where it does not apply
+                double nvb = 0.0;
+                if (w >= QK && n <= w) {
                     const double wn = (n == w) ? wa : solve(s.raw[B][16 * n + c][g]);
-                    const double nvb = PANEL_MFMA4(rA, wn, 0.0);                       // -w / d, component g
-                    acc[n] = PANEL_MFMA(wa, nvb, acc[n]);
+                    nvb = PANEL_MFMA4(rA, wn, 0.0);                                    // -w / d, component g
                 }
+                acc[n] = PANEL_MFMA(wa, nvb, acc[n]);
             }
         }
         // finished entries of columns K..K+3: zeros above the diagonal and for the waves above the block
