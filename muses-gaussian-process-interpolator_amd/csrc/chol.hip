@@ -232,7 +232,7 @@ extern "C" int mgpi_debug_read_trace(unsigned long long* host, unsigned* n) {
 #define PT_STAMP(k) do { } while (0)
 #define PT_FLUSH(role) do { } while (0)
 #endif
-template <bool MX, bool MXF>
+template <bool MX, int MXF>
 __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__ A, int64_t lda, int64_t c0, int has_prev, int nfused,
                                                          int rest_cols, int64_t pivot_base, const double* __restrict__ diag0,
                                                          int* __restrict__ info, double* __restrict__ S, double ptol, int mode,
@@ -287,9 +287,9 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__
             panel_gemm_nt(accD, A + (c0 + 16 * w + c) * lda + kk + 2 * g, A + (c0 + c) * lda + kk + 2 * g, lda, 0, w + 1);
         int bad = 0;
         PT_STAMP(1);
-        if constexpr (MXF) {
+        if constexpr (MXF != 0) {
             panel_mx_state mxs = panel_mx_begin(s, tid, g, c);
-            potf2_acc_mx<0>::run(accD, s, w, g, c, bad, b == 0 ? S : nullptr, mxs);
+            potf2_acc_mx<0, MXF == 1>::run(accD, s, w, g, c, bad, b == 0 ? S : nullptr, mxs);
         } else {
             potf2_acc_rounds<0>::run(accD, s, w, g, c, bad, b == 0 ? S : nullptr);
         }
@@ -333,9 +333,10 @@ typedef void (*panel_step_fn)(double*, int64_t, int64_t, int, int, int, int64_t,
                               int64_t, int64_t);
 static panel_step_fn panel_step_entry() {
     static const bool mx = getenv("MGPI_PANEL_MX") ? atoi(getenv("MGPI_PANEL_MX")) != 0 : true;
-    static const bool mxf = getenv("MGPI_PANEL_MX_FACTOR") ? atoi(getenv("MGPI_PANEL_MX_FACTOR")) != 0 : false;
-    if (mxf) return mx ? panel_step_kernel<true, true> : panel_step_kernel<false, true>;
-    return mx ? panel_step_kernel<true, false> : panel_step_kernel<false, false>;
+    static const int mxf = getenv("MGPI_PANEL_MX_FACTOR") ? atoi(getenv("MGPI_PANEL_MX_FACTOR")) : 0;
+    if (mxf == 1) return mx ? panel_step_kernel<true, 1> : panel_step_kernel<false, 1>;
+    if (mxf == 2) return mx ? panel_step_kernel<true, 2> : panel_step_kernel<false, 2>;
+    return mx ? panel_step_kernel<true, 0> : panel_step_kernel<false, 0>;
 }
 
 // one step: diagonal block at (c0, c0) of the matrix A (c0 absolute), `rows_below` rows below the block, the panel ends at

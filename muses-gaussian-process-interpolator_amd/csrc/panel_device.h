@@ -357,9 +357,12 @@ struct potf2_acc_rounds {
         const double ig = rsq_refined(dg);
         auto solve = [&](const panel_double4_t& a, int rw) -> double {
             const double w0 = a[0];
-            const double w1 = fma(-w0, m10, a[1]);
-            const double w2 = fma(-w1, m21, fma(-w0, m20, a[2]));
-            const double w3 = fma(-w2, m32, fma(-w1, m31, fma(-w0, m30, a[3])));
+            double w1 = fma(-w0, m10, a[1]);
+            double w2 = fma(-w1, m21, fma(-w0, m20, a[2]));
+            double w3 = fma(-w2, m32, fma(-w1, m31, fma(-w0, m30, a[3])));
+            // all four components in every lane, THEN the pick: left alone the compiler sinks each fma into a branch on g -
+            // every wave holds all four g, so the branches save nothing and cost compares, EXEC-masked regions and copies
+            __asm__ volatile("" : "+v"(w1), "+v"(w2), "+v"(w3));
             const double wg = (g == 0) ? w0 : (g == 1) ? w1 : (g == 2) ? w2 : w3;
             return (rw >= K + g) ? wg : 0.0;                         // rows above column K + g's diagonal: nothing
         };
@@ -526,7 +529,11 @@ struct panel_mx_state {
     bool diag;
 };
 
-template <int K>
+// MATRIX_CHAIN = false: the HYBRID - the pivot recurrence stays on the vector pipe (uniform arithmetic in every lane, the same
+// sign conventions: nrd = -1 / d, nm = -m), everything per row goes to the matrix pipe.  The recurrence is the shorter chain
+// there when the kernel runs alone (18 dependent v_fma_f64 at 40 cycles), and none of the selects, compares and EXEC-masked
+// regions the compiler makes of the vector row solves remain.
+template <int K, bool MATRIX_CHAIN>
 struct potf2_acc_mx {
     static __device__ __forceinline__ void run(panel_double4_t (&acc)[4], panel_lds& s, int w, int g, int c, int& bad,
                                                double* __restrict__ S, panel_mx_state& st) {
@@ -536,33 +543,57 @@ struct potf2_acc_mx {
             for (int r = 0; r < 4; ++r) s.raw[B][16 * w + g + 4 * r][c - KL] = acc[QK][r];
         }
         __syncthreads();
-        // pivot block as s I_4 (lower part), raw[B][K + i][j] at offset ((B * IB + K + i) * 4 + j)
-        const double* pb = st.pb + (B * IB + K) * 4;
-        const double P00 = pb[0], P10 = pb[4], P11 = pb[5], P20 = pb[8], P21 = pb[9], P22 = pb[10];
-        const double P30 = pb[12], P31 = pb[13], P32 = pb[14], P33 = pb[15];
         const int row = 16 * w + c;
         const double a = s.raw[B][row][g];                       // own row, component g
-        auto nrecip = [&](double d) -> double {                 // -1 / d on the diagonal lanes (0 elsewhere)
-            double ns = st.ns;
-            if (st.diag) ns = __builtin_amdgcn_rcp(-d);
-            const double e = PANEL_MFMA4(d, ns, st.one);         // 1 + d ns
-            return PANEL_MFMA4(e, ns, ns);                       // ns + ns e
-        };
-        const double d0 = P00;
-        const double nrd0 = nrecip(d0);
-        const double nm10 = PANEL_MFMA4(P10, nrd0, 0.0), nm20 = PANEL_MFMA4(P20, nrd0, 0.0), nm30 = PANEL_MFMA4(P30, nrd0, 0.0);
-        const double d1 = PANEL_MFMA4(nm10, P10, P11);
-        const double q21 = PANEL_MFMA4(nm20, P10, P21), q31 = PANEL_MFMA4(nm30, P10, P31);
-        const double u22 = PANEL_MFMA4(nm20, P20, P22), u32 = PANEL_MFMA4(nm30, P20, P32), u33 = PANEL_MFMA4(nm30, P30, P33);
-        const double nrd1 = nrecip(d1);
-        const double nm21 = PANEL_MFMA4(q21, nrd1, 0.0), nm31 = PANEL_MFMA4(q31, nrd1, 0.0);
-        const double d2 = PANEL_MFMA4(nm21, q21, u22);
-        const double q32 = PANEL_MFMA4(nm31, q21, u32);
-        const double v33 = PANEL_MFMA4(nm31, q31, u33);
-        const double nrd2 = nrecip(d2);
-        const double nm32 = PANEL_MFMA4(q32, nrd2, 0.0);
-        const double d3 = PANEL_MFMA4(nm32, q32, v33);
-        const double nrd3 = nrecip(d3);
+        double d0, d1, d2, d3, nrd0, nrd1, nrd2, nrd3, nm10, nm20, nm30, nm21, nm31, nm32;
+        if constexpr (MATRIX_CHAIN) {
+            // pivot block as s I_4 (lower part), raw[B][K + i][j] at offset ((B * IB + K + i) * 4 + j)
+            const double* pb = st.pb + (B * IB + K) * 4;
+            const double P00 = pb[0], P10 = pb[4], P11 = pb[5], P20 = pb[8], P21 = pb[9], P22 = pb[10];
+            const double P30 = pb[12], P31 = pb[13], P32 = pb[14], P33 = pb[15];
+            auto nrecip = [&](double d) -> double {             // -1 / d on the diagonal lanes (0 elsewhere)
+                double ns = st.ns;
+                if (st.diag) ns = __builtin_amdgcn_rcp(-d);
+                const double e = PANEL_MFMA4(d, ns, st.one);     // 1 + d ns
+                return PANEL_MFMA4(e, ns, ns);                   // ns + ns e
+            };
+            d0 = P00;
+            nrd0 = nrecip(d0);
+            nm10 = PANEL_MFMA4(P10, nrd0, 0.0); nm20 = PANEL_MFMA4(P20, nrd0, 0.0); nm30 = PANEL_MFMA4(P30, nrd0, 0.0);
+            d1 = PANEL_MFMA4(nm10, P10, P11);
+            const double q21 = PANEL_MFMA4(nm20, P10, P21), q31 = PANEL_MFMA4(nm30, P10, P31);
+            const double u22 = PANEL_MFMA4(nm20, P20, P22), u32 = PANEL_MFMA4(nm30, P20, P32), u33 = PANEL_MFMA4(nm30, P30, P33);
+            nrd1 = nrecip(d1);
+            nm21 = PANEL_MFMA4(q21, nrd1, 0.0); nm31 = PANEL_MFMA4(q31, nrd1, 0.0);
+            d2 = PANEL_MFMA4(nm21, q21, u22);
+            const double q32 = PANEL_MFMA4(nm31, q21, u32);
+            const double v33 = PANEL_MFMA4(nm31, q31, u33);
+            nrd2 = nrecip(d2);
+            nm32 = PANEL_MFMA4(q32, nrd2, 0.0);
+            d3 = PANEL_MFMA4(nm32, q32, v33);
+            nrd3 = nrecip(d3);
+        } else {
+            const double p00 = s.raw[B][K][0], p10 = s.raw[B][K + 1][0], p20 = s.raw[B][K + 2][0], p30 = s.raw[B][K + 3][0];
+            const double p11 = s.raw[B][K + 1][1], p21 = s.raw[B][K + 2][1], p31 = s.raw[B][K + 3][1];
+            const double p22 = s.raw[B][K + 2][2], p32 = s.raw[B][K + 3][2], p33 = s.raw[B][K + 3][3];
+            auto nrecip = [](double d) -> double {              // -1 / d: estimate of 1 / (-d) + one Newton step
+                const double p = __builtin_amdgcn_rcp(-d);
+                return fma(p, fma(d, p, 1.0), p);
+            };
+            d0 = p00;
+            nrd0 = nrecip(d0);
+            nm10 = p10 * nrd0; nm20 = p20 * nrd0; nm30 = p30 * nrd0;
+            d1 = fma(nm10, p10, p11);
+            nrd1 = nrecip(d1);
+            const double q21 = fma(nm20, p10, p21), q31 = fma(nm30, p10, p31);
+            nm21 = q21 * nrd1; nm31 = q31 * nrd1;
+            d2 = fma(nm21, q21, fma(nm20, p20, p22));
+            nrd2 = nrecip(d2);
+            const double q32 = fma(nm31, q21, fma(nm30, p20, p32));
+            nm32 = q32 * nrd2;
+            d3 = fma(nm32, q32, fma(nm31, q31, fma(nm30, p30, p33)));
+            nrd3 = nrecip(d3);
+        }
         // the images: lane 0 of the wave holds every one of these scalars (it is a diagonal lane)
         if ((threadIdx.x & 63) == 0) {
             s.mA[w][1][0] = nm10; s.mA[w][2][0] = nm20; s.mA[w][2][1] = nm21;
@@ -598,7 +629,7 @@ struct potf2_acc_mx {
         if (row == K + g) s.invd[K + g] = ig;
         if (S != nullptr) S[(int64_t)row * IB + K + g] = x;
         if constexpr (K + 4 < IB) {
-            potf2_acc_mx<K + 4>::run(acc, s, w, g, c, bad, S, st);
+            potf2_acc_mx<K + 4, MATRIX_CHAIN>::run(acc, s, w, g, c, bad, S, st);
         } else {
             if (w == 0) {                                        // the pivots against their thresholds, once
                 const int l = threadIdx.x & 63;

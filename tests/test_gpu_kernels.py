@@ -241,7 +241,7 @@ def test_trtri_neg_strided_batch(ctx, w, batch, row_step, col_step):
                                  {'MGPI_TRSM_SUPER': '4', 'MGPI_TRSM_SUPER_MIN': '512'},
                                  {'MGPI_PANEL_STEP': '0'}, {'MGPI_PANEL_STEP_SPLIT': '0', 'MGPI_PANEL_STEP_ROWS': '512'},
                                  {'MGPI_PANEL_STEP_ROWS': '0'}, {'MGPI_PANEL_STEP_ROWS': '1000000', 'MGPI_SUPER_MIN': '512'},
-                                 {'MGPI_POTRF_MERGED': '0'}, {'MGPI_PANEL_MX': '0'}, {'MGPI_PANEL_MX': '0', 'MGPI_SUPER_MIN': '512'}, {'MGPI_PANEL_MX_FACTOR': '1'},
+                                 {'MGPI_POTRF_MERGED': '0'}, {'MGPI_PANEL_MX': '0'}, {'MGPI_PANEL_MX': '0', 'MGPI_SUPER_MIN': '512'}, {'MGPI_PANEL_MX_FACTOR': '1'}, {'MGPI_PANEL_MX_FACTOR': '2'}, {'MGPI_PANEL_MX_FACTOR': '2', 'MGPI_SUPER_MIN': '512'},
                                  {'MGPI_PANEL_MX_FACTOR': '1', 'MGPI_PANEL_MX': '0', 'MGPI_SUPER_MIN': '512'}, {'MGPI_TAIL_ROWS': '0'}, {'MGPI_TAIL_ROWS': '1024'}, {'MGPI_TAIL_ROWS': '4096'}, {'MGPI_TAIL_ROWS': '4096', 'MGPI_SUPER_MIN': '512'}, {'MGPI_PANEL_LEFT_ROWS': '0'}, {'MGPI_PANEL_LEFT_ROWS': '0', 'MGPI_PANEL_STEP_ROWS': '0'},
                                  {'MGPI_PANEL_INNER': '512'}, {'MGPI_PANEL_INNER': '128', 'MGPI_PANEL_INNER_ROWS': '0'}, {'MGPI_PANEL_INNER': '256', 'MGPI_PANEL_INNER_ROWS': '0', 'MGPI_MERGED_MIN': '0'}, {'MGPI_MERGED_MIN': '0'}, {'MGPI_MERGED_MIN': '0', 'MGPI_SUPER_MIN': '512'},
                                  {'MGPI_COV_FAST': '0'}, {'MGPI_PREDICT_MFMA': '1'}, {'MGPI_GEMM_SKINNY_TILES': '0'}, {'MGPI_BCAST': 'rccl'}, {}],
