@@ -1614,6 +1614,7 @@ extern "C" int mgpi_potrs(mgpi_ctx* ctx, const mgpi_mat* L, const double* b, int
 // column-role workgroup per 64 rows applies the previous step's columns to its rows of the current column block
 // (deferred right-looking update), builds the LDS images of the 64 x 64 diagonal sub-block and substitutes; update-role
 // workgroups apply the previous columns to the remaining column blocks.  One launch per step instead of two.
+template <bool MX>
 __global__ __launch_bounds__(256, 2) void trsm_right_step_kernel(double* __restrict__ A, int64_t lda, int nrowblk,
                                                                  const double* __restrict__ Lk, int64_t ldl, int64_t c0, int has_prev,
                                                                  int rest_cols) {
@@ -1643,7 +1644,12 @@ __global__ __launch_bounds__(256, 2) void trsm_right_step_kernel(double* __restr
     }
     if (tid < IB) s.invd[tid] = 1.0 / Lk[(c0 + tid) * ldl + c0 + tid];
     __syncthreads();
-    trsm_acc_rounds<0>::run(acc, s, w, g, c, A + (r0 + 16 * w + c) * lda + c0);
+    if constexpr (MX) {
+        panel_trsm_images(s, tid);
+        trsm_acc_mx<0>::run(acc, s, w, g, c, A + (r0 + 16 * w + c) * lda + c0);
+    } else {
+        trsm_acc_rounds<0>::run(acc, s, w, g, c, A + (r0 + 16 * w + c) * lda + c0);
+    }
 }
 
 extern "C" int mgpi_trsm_right_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* A) {
@@ -1659,8 +1665,13 @@ extern "C" int mgpi_trsm_right_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* A
         for (int64_t c0 = 0; c0 < w; c0 += IB) {
             const int has_prev = c0 > 0;
             const int rest_cols = has_prev ? (int)((w - c0 - IB) / IB) : 0;
-            hipLaunchKernelGGL(trsm_right_step_kernel, dim3((unsigned)(nrowblk * (1 + rest_cols))), dim3(256), 0, ctx->stream, A->d, A->ld,
-                               nrowblk, L->d, L->ld, c0, has_prev, rest_cols);
+            static const bool mx = getenv("MGPI_PANEL_MX") ? atoi(getenv("MGPI_PANEL_MX")) != 0 : true;      // as in the step kernel
+            if (mx)
+                hipLaunchKernelGGL(trsm_right_step_kernel<true>, dim3((unsigned)(nrowblk * (1 + rest_cols))), dim3(256), 0, ctx->stream, A->d,
+                                   A->ld, nrowblk, L->d, L->ld, c0, has_prev, rest_cols);
+            else
+                hipLaunchKernelGGL(trsm_right_step_kernel<false>, dim3((unsigned)(nrowblk * (1 + rest_cols))), dim3(256), 0, ctx->stream, A->d,
+                                   A->ld, nrowblk, L->d, L->ld, c0, has_prev, rest_cols);
         }
         MGPI_HIP_TRY(hipGetLastError());
         return 0;
