@@ -442,7 +442,7 @@ def main():
             tr_flops = step.gp.trailing_flops / (args.steps + args.warmup)      # this rank's share, per step
         tflops_dom = tr_flops * args.steps / (dom_ms * 1e-3) / 1e12
         if c5:
-            kernel_name = 'gemm_f64_pipe_kernel<NN> (update launches of V = L^-1 K*^T, the variance solve)'
+            kernel_name = 'gemm_f64_pipe_kernel<NN> (update launches of V = L^-1 K*^T, the variance solve; main and look-ahead stream)'
             data_desc = 'stellarcollapse-shaped table (ye x logrho x logenergy -> logtemp, per-axis downsample %d)' % WORKLOADS[args.workload][0]
         else:
             kernel_name = 'gemm_f64_pipe_kernel<NT%s> (Cholesky trailing update%s)' % ((',lower', ', syrk') if not distributed else ('', ', rank 0 local blocks'))

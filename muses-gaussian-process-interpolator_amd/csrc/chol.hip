@@ -1128,8 +1128,13 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
                 ctx->lean = 0;
                 if (rc) return rc;
                 const int64_t p1 = p0 + w, rem = r0 + wc - p1;
-                if (rem > 0)    // B[p1:r0+wc,:] -= L[p1:r0+wc, p0:p1] * B[p0:p1,:]
-                    MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, rem, nc, w, L + p1 * lda + p0, lda, X + p0 * ldb, ldb, B + p1 * ldb, ldb));
+                if (rem > 0) {  // B[p1:r0+wc,:] -= L[p1:r0+wc, p0:p1] * B[p0:p1,:]
+                    mgpi_prof_begin(ctx, 4);     // the update launches of BOTH streams are timed: with deep super-blocks a good part
+                    int rcu = mgpi_launch_gemm(ctx, 0, 1, 0, rem, nc, w, L + p1 * lda + p0, lda, X + p0 * ldb, ldb, B + p1 * ldb, ldb);
+                    mgpi_prof_end(ctx, 4);       // of the solve's flops runs inside the super-block, on the look-ahead stream
+                    mgpi_prof_flops(ctx, 4, 2.0 * (double)rem * (double)nc * (double)w);
+                    MGPI_TRY(rcu);
+                }
             }
             return 0;
         };
@@ -1152,7 +1157,10 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
                 // second stream: B[r1:r1+w1,:] -= L[r1:r1+w1, r0:r0+w] * B[r0:r0+w,:], then solve that (super-)block
                 MGPI_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_upd, 0));                        // update k-1 of these rows done
                 ctx->stream = ctx->stream2;
+                mgpi_prof_begin(ctx, 4);
                 int rc = mgpi_launch_gemm(ctx, 0, 1, 0, w1, nc, w, L + r1 * lda + r0, lda, X + r0 * ldb, ldb, B + r1 * ldb, ldb);
+                mgpi_prof_end(ctx, 4);
+                mgpi_prof_flops(ctx, 4, 2.0 * (double)w1 * (double)nc * (double)w);
                 if (rc == 0) rc = solve_super(r1, w1, true);
                 ctx->stream = main_stream;
                 MGPI_TRY(rc);
