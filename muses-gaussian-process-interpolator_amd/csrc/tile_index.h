@@ -26,7 +26,9 @@ MGPI_HD void tri_decode(int64_t idx, int& ti, int& tj) {
 // column-major, so 64 consecutive tiles (= what one XCD has in flight: 32 CUs x 2 workgroups) form an 8 x 8 block
 // that shares 8 A slabs and 8 B slabs through that XCD's 4 MiB L2.  With plain row-major order every tile
 // pulled its own B slab from beyond L2 (measured: 54 % L2 hit rate, 2.5x the algorithmic HBM bytes).
-#define GEMM_BAND 8
+#ifndef GEMM_BAND
+#define GEMM_BAND 8      // 4 and 16 measured: see DESIGN.md (traffic per tile, isolated rate)
+#endif
 template <bool LOWER>
 MGPI_HD void tile_decode(int64_t idx, int tm, int tn, int& ti, int& tj) {
     constexpr int S = GEMM_BAND;
