@@ -955,6 +955,22 @@ __global__ __launch_bounds__(256) void ll_finish_kernel(const double* __restrict
         out[blockIdx.x] = (info[blockIdx.x] != 0) ? -INFINITY : -0.5 * part[0][0] - part[1][0] - 0.5 * (double)n * 1.8378770664093453;
 }
 
+static int trsv_pair(mgpi_ctx* ctx, const mgpi_mat* Lm, double* v, bool fwd_only);
+
+// *out = sum_i v[i]^2, one workgroup (the quadratic form of the sequential log-likelihood path)
+__global__ __launch_bounds__(256) void sumsq_kernel(const double* __restrict__ v, int64_t n, double* __restrict__ out) {
+    __shared__ double part[256];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) acc = fma(v[i], v[i], acc);
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = part[0];
+}
+
 extern "C" int mgpi_loglikelihood_batch(mgpi_ctx* ctx, const mgpi_mat* X, const mgpi_mat* f, const mgpi_kernel_desc* terms, int nterms,
                                         int batch, double* out, int32_t* info) {
     MGPI_REQUIRE(ctx && X && f && terms && out, "mgpi_loglikelihood_batch: null pointer");
@@ -971,8 +987,6 @@ extern "C" int mgpi_loglikelihood_batch(mgpi_ctx* ctx, const mgpi_mat* X, const 
         mgpi_mat *K = nullptr, *a = nullptr;
         int st = mgpi_mat_alloc_wide(ctx, n, n, &K);
         if (st == 0) st = mgpi_mat_alloc(ctx, n, 1, &a);
-        std::vector<double> fh((size_t)n), ah((size_t)n);
-        if (st == 0) st = mgpi_mat_download(f, fh.data(), 1);
         for (int b = 0; b < batch && st == 0; ++b) {
             double logdet = 0.0;
             st = mgpi_cov_matrix_dev(ctx, X, nullptr, terms + (size_t)b * nterms, nterms, 1, K);
@@ -983,12 +997,17 @@ extern "C" int mgpi_loglikelihood_batch(mgpi_ctx* ctx, const mgpi_mat* X, const 
                 st = 0;
                 continue;
             }
+            // f^T K^-1 f = |L^-1 f|^2: the forward sweep only, the sum of squares on the device, one scalar back
             if (st == 0) st = mgpi_mat_copy(ctx, f, a);
-            if (st == 0) st = mgpi_potrs_dev(ctx, K, a);
-            if (st == 0) st = mgpi_mat_download(a, ah.data(), 1);
+            if (st == 0) st = trsv_pair(ctx, K, a->d, true);
             if (st == 0) {
                 double q = 0.0;
-                for (int64_t i = 0; i < n; ++i) q += fh[i] * ah[i];
+                double* dq = ctx->d_scal + 3;
+                hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, ctx->stream, a->d, n, dq);
+                double* land = ctx->h_pinned ? (double*)ctx->h_pinned : &q;
+                MGPI_HIP_TRY(hipMemcpyAsync(land, dq, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+                q = *land;
                 out[b] = -0.5 * q - 0.5 * logdet - 0.5 * (double)n * 1.8378770664093453;
                 if (info) info[b] = 0;
             }
@@ -1562,7 +1581,8 @@ static void launch_trsv_update(hipStream_t stream, const double* L, int64_t lda,
 // so that only the next block's entries stay on the chain and the rest runs on the second stream was measured and
 // dropped: the event record/wait pairs it puts on the chain cost more than the ~15 us gemv they take off it
 // (11.4 vs 10.3 ms at N = 32768, 2.55 vs 2.15 ms at N = 8192).
-static int trsv_pair(mgpi_ctx* ctx, const mgpi_mat* Lm, double* v) {
+// fwd_only: stop after L y = f (what the quadratic form f^T K^-1 f = y^T y of the log-likelihood needs)
+static int trsv_pair(mgpi_ctx* ctx, const mgpi_mat* Lm, double* v, bool fwd_only) {
     const int64_t pn = Lm->prows <= Lm->pcols ? Lm->prows : mgpi_roundup(Lm->rows, IB);
     const int64_t lda = Lm->ld;
     const int64_t nb = ctx->nb;
@@ -1575,7 +1595,7 @@ static int trsv_pair(mgpi_ctx* ctx, const mgpi_mat* Lm, double* v) {
         const int w1 = (int)((pn - r1 < nb) ? (pn - r1) : nb);
         launch_trsv_update(ctx->stream, L, lda, v, r0, w, r1, pn - r1, 0, w1 > 0 ? L + r1 * lda + r1 : nullptr, w1);
     }
-    for (int64_t b = nblk - 1; b >= 0; --b) {
+    for (int64_t b = fwd_only ? -1 : nblk - 1; b >= 0; --b) {
         const int64_t r0 = b * nb;
         const int w = (int)((pn - r0 < nb) ? (pn - r0) : nb);
         launch_trsv_diag(ctx, L + r0 * lda + r0, lda, v + r0, w, 1);
@@ -1595,7 +1615,7 @@ extern "C" int mgpi_potrs_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* B) {
     MGPI_REQUIRE(B->rows == L->rows, "mgpi_potrs_dev: B has %lld rows, L is %lld", (long long)B->rows, (long long)L->rows);
     MGPI_REQUIRE(B->prows >= L->prows, "mgpi_potrs_dev: B row padding smaller than L's");
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
-    if (B->cols == 1 && B->ld == 1) return trsv_pair(ctx, L, B->d);
+    if (B->cols == 1 && B->ld == 1) return trsv_pair(ctx, L, B->d, false);
     MGPI_REQUIRE(B->pcols % 64 == 0, "mgpi_potrs_dev: a multi-column B must be tile padded (cols > %d)", MGPI_MAX_D);
     MGPI_TRY(trsm_blocked(ctx, L, B->d, B->ld, B->pcols, 0));
     return trsm_blocked(ctx, L, B->d, B->ld, B->pcols, 1);
