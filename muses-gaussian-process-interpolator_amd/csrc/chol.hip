@@ -3,10 +3,9 @@
 // (mgpi/interpolators.py:92,179,339,343): alpha = L^-T L^-1 f, logdet = 2 sum log L_ii.
 //
 // Two-level blocking: outer block nb (ctx->nb, default 512) for the trailing update on fp64 MFMA (gemm.hip),
-// inner block 64 for the panel: 64x64 potf2 (four lanes per row, registers + a 1 KB LDS column buffer), 64-wide
-// row trsm (four lanes per row, L_jj as an LDS coefficient image), MFMA gemm for the panel-internal
-// (left-looking) updates.  Look-ahead of depth one: panel k+1 is factored on a second stream, with kernels lean
-// enough to start beside two resident trailing-update workgroups, while the trailing update of panel k runs.
+// inner block 64 for the panel: one launch per 64-column step (panel_step_kernel: deferred right-looking update, 64 x 64
+// Cholesky and 64-row substitution, all in MFMA accumulator layout, panel_device.h).  Look-ahead of depth one: panel k+1
+// is factored on a second stream while the trailing update of panel k runs.
 #include "mgpi_internal.h"
 #include <math.h>
 #include <vector>
@@ -37,152 +36,6 @@ struct mgpi_stream_join_guard {
     }
 };
 
-// 256 threads: FOUR lanes (one DPP quad) share row r of the block, lane part q owning columns [16q, 16q+16) in 16
-// registers (every register index is a compile-time constant after unrolling).  Column k: the owning parts drop
-// their entry of column k into LDS (rows above k write 0), one barrier, every lane reads the pivot and the 16
-// column entries that face its own columns, forms 1/sqrt(pivot) and applies a_r[j] -= (a_r[k]/pivot) a_j[k].
-// Footprint 1.5 KB of LDS and < 104 VGPRs on purpose: with the look-ahead this kernel has to be able to start on
-// a CU that already runs two trailing-update workgroups (128 KB LDS, 2 x 200 VGPRs per SIMD) instead of waiting
-// ~300 us for one of them to finish (an earlier single-wave version held the row in 128 VGPRs and a 33 KB
-// staging tile and did wait).
-__global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int64_t lda, int64_t pivot_base,
-                                                    const double* __restrict__ diag0, int* __restrict__ info, double ptol) {
-    __shared__ __attribute__((aligned(16))) double col[2][4][IB];
-    __shared__ double dtol[IB];
-    MGPI_CHAIN_PRIO();
-    const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
-    double* row = A + (int64_t)r * lda + 16 * q;
-    double a[16];
-#pragma unroll
-    for (int j = 0; j < 16; j += 2) {
-        const double2 v = *reinterpret_cast<const double2*>(row + j);
-        a[j] = (16 * q + j <= r) ? v.x : 0.0;           // only the lower triangle is read
-        a[j + 1] = (16 * q + j + 1 <= r) ? v.y : 0.0;
-    }
-    if (q == 0) dtol[r] = ptol * fabs(diag0[r]);
-    int bad = 0;
-    potf2_rounds<0>::run(a, col, dtol, r, q, bad);
-#pragma unroll
-    for (int j = 0; j < 16; j += 2) {
-        const double2 v = make_double2((16 * q + j <= r) ? a[j] : 0.0, (16 * q + j + 1 <= r) ? a[j + 1] : 0.0);
-        *reinterpret_cast<double2*>(row + j) = v;
-    }
-    if (tid == 0 && bad != 0) {
-        const int cand = (int)(pivot_base + bad);
-        int old = atomicCAS(info, 0, cand);
-        while (old != 0 && old > cand) {
-            const int prev = atomicCAS(info, old, cand);
-            if (prev == old) break;
-            old = prev;
-        }
-    }
-}
-
-int mgpi_launch_potf2(mgpi_ctx* ctx, double* A, int64_t lda, int64_t pivot_base, const double* diag0) {
-    hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, pivot_base, diag0, ctx->d_info, ctx->pivot_tol);
-    MGPI_HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-// panel trsm: X L_jj^T = A, 64 columns; one 256-thread workgroup = 64 rows, 4 lanes per row.
-// x_k = (a_k - sum_{m<k} x_m L[k][m]) / L[k][k]: forward sweep with C[k][m] = L[m][k] (m > k).
-__global__ __launch_bounds__(256) void trsm_rows_kernel(const double* __restrict__ Ljj, int64_t ldl,
-                                                        double* __restrict__ A, int64_t lda) {
-    __shared__ __attribute__((aligned(16))) double C[IB][IB];
-    MGPI_CHAIN_PRIO();
-    const int tid = threadIdx.x, q = tid & 3;
-    stage_coeff<true, true>(Ljj, ldl, C, tid);
-    double* row = A + ((int64_t)blockIdx.x * IB + (tid >> 2)) * lda + 16 * q;
-    double x[16];
-#pragma unroll
-    for (int j = 0; j < 16; j += 2) {
-        const double2 v = *reinterpret_cast<const double2*>(row + j);
-        x[j] = v.x;
-        x[j + 1] = v.y;
-    }
-    __syncthreads();
-    quad_sweep<IB - 1, true>::run(x, C, q);
-#pragma unroll
-    for (int j = 0; j < 16; j += 2) *reinterpret_cast<double2*>(row + j) = make_double2(x[j], x[j + 1]);
-}
-
-int mgpi_launch_trsm_rows(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double* A, int64_t lda, int64_t rows) {
-    if (rows == 0) return 0;
-    MGPI_REQUIRE(rows % IB == 0, "trsm_rows: rows=%lld not a multiple of %d", (long long)rows, IB);
-    hipLaunchKernelGGL(trsm_rows_kernel, dim3((unsigned)(rows / IB)), dim3(256), 0, ctx->stream, Ljj, ldl, A, lda);
-    MGPI_HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-// potf2 + panel trsm in ONE launch: every workgroup factors the 64 x 64 diagonal block itself (the same arithmetic in
-// the same order, so all copies are identical), workgroup 0 stores it and reports a failed pivot, workgroup b >= 1
-// solves row block b - 1 below it against the factor it holds in registers - the coefficient image is written to LDS
-// straight from those registers, and the rows to solve are fetched before the factorisation starts, so their load
-// latency hides behind it.  One kernel boundary less on the panel chain (potf2 26 us + trsm 22 us stand-alone).
-__global__ __launch_bounds__(256) void potf2_trsm_kernel(double* __restrict__ A, int64_t lda, int64_t pivot_base,
-                                                         const double* __restrict__ diag0, int* __restrict__ info,
-                                                         double* __restrict__ S, double ptol) {
-    __shared__ __attribute__((aligned(16))) double col[2][4][IB];
-    __shared__ double dtol[IB];
-    __shared__ __attribute__((aligned(16))) double C[IB][IB];
-    MGPI_CHAIN_PRIO();
-    const int tid = threadIdx.x, r = tid >> 2, q = tid & 3;
-    const double* drow = A + (int64_t)r * lda + 16 * q;
-    double a[16];
-#pragma unroll
-    for (int j = 0; j < 16; j += 2) {
-        const double2 v = *reinterpret_cast<const double2*>(drow + j);
-        a[j] = (16 * q + j <= r) ? v.x : 0.0;           // only the lower triangle is read
-        a[j + 1] = (16 * q + j + 1 <= r) ? v.y : 0.0;
-    }
-    if (q == 0) dtol[r] = ptol * fabs(diag0[r]);
-    double* xrow = A + ((int64_t)blockIdx.x * IB + r) * lda + 16 * q;     // workgroup b: rows [64 b, 64 b + 64) below the block's top
-    double x[16];
-    if (blockIdx.x > 0) {
-#pragma unroll
-        for (int j = 0; j < 16; j += 2) {
-            const double2 v = *reinterpret_cast<const double2*>(xrow + j);
-            x[j] = v.x;
-            x[j + 1] = v.y;
-        }
-    }
-    int bad = 0;
-    potf2_rounds<0>::run(a, col, dtol, r, q, bad);
-    if (blockIdx.x == 0) {
-        // NOT in place: the other workgroups of this launch may not have read the unfactored block yet (with 512 of them
-        // and a busy chip some start long after this one is done).  The factor goes to the scratch strip S (64 wide) and
-        // is copied over the diagonal blocks when the whole factorisation is done (diag_blocks_back_kernel); nothing in
-        // between reads a diagonal block that has been factored.
-        double* row = S + (int64_t)r * IB + 16 * q;
-#pragma unroll
-        for (int j = 0; j < 16; j += 2) {
-            const double2 v = make_double2((16 * q + j <= r) ? a[j] : 0.0, (16 * q + j + 1 <= r) ? a[j + 1] : 0.0);
-            *reinterpret_cast<double2*>(row + j) = v;
-        }
-        if (tid == 0 && bad != 0) {
-            const int cand = (int)(pivot_base + bad);
-            int old = atomicCAS(info, 0, cand);
-            while (old != 0 && old > cand) {
-                const int prev = atomicCAS(info, old, cand);
-                if (prev == old) break;
-                old = prev;
-            }
-        }
-        return;
-    }
-    // coefficient image of the forward sweep X L^T = A:  C[k][m] = L[m][k] (m > k), 1 / L[k][k] (m == k), 0 (m < k);
-    // this thread holds L[r][16 q + j]
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int k = 16 * q + j;
-        C[k][r] = (k < r) ? a[j] : ((k == r) ? 1.0 / a[j] : 0.0);
-    }
-    __syncthreads();
-    quad_sweep<IB - 1, true>::run(x, C, q);
-#pragma unroll
-    for (int j = 0; j < 16; j += 2) *reinterpret_cast<double2*>(xrow + j) = make_double2(x[j], x[j + 1]);
-}
-
 // ---- ONE launch per 64-column step of a panel (round 2) -----------------------------------------------------------------
 // Step j of a panel (diagonal block at row / column c0) used to be three launches on the chain the trailing update waits
 // for: potf2 (or potf2+trsm fused), the row trsm, and the right-looking gemm that applies the 64 new columns to the rest
@@ -191,8 +44,9 @@ __global__ __launch_bounds__(256) void potf2_trsm_kernel(double* __restrict__ A,
 //     X' (rows >= c0, columns [c0 - 64, c0)) to ITS rows of column block [c0, c0 + 64) and - redundantly, every workgroup -
 //     to the diagonal block, factors that 64 x 64 block, solves its rows against it, stores them.  The products land in
 //     MFMA accumulators, which is also the layout the factorisation and the substitution run in (panel_device.h).
-//     Workgroup 0 owns the diagonal block's rows: it stores the factor (to the scratch strip S, like potf2_trsm_kernel:
-//     late workgroups of this launch still read the unfactored block) and reports a failed pivot.
+//     Workgroup 0 owns the diagonal block's rows: it stores the factor (to the scratch strip S, NOT in place: late
+//     workgroups of this launch still read the unfactored block; diag_blocks_back_kernel copies the strip over the
+//     diagonal blocks when the whole factorisation is done) and reports a failed pivot.
 //   * workgroups >= nfused ("update role"): one 64 x 64 tile each of the REST of the panel (column blocks right of this
 //     step's), to which they apply X' - the part of the deferred gemm that is not on this step's critical path.
 // The chain per step is then one launch of (two contraction-64 products + 64 x 64 Cholesky + 64-row substitution).
@@ -201,12 +55,8 @@ __global__ __launch_bounds__(256) void potf2_trsm_kernel(double* __restrict__ A,
 // Measured and dropped: folding the PREVIOUS panel's trailing update (contraction 512) into the column role, to take the
 // skinny column-update gemm off the chain - with operands streamed straight from L2 the 64 x 64 x 512 products per
 // workgroup made a step 2x slower (N = 8192: potrf 13.8 ms against 7.5).
-// `has_prev` counts the previous 64-column blocks a column-role workgroup applies: 1 = the right-looking form above; j at step
-// j = LEFT-looking (every earlier block of the panel, no update-role workgroups at all).  Meant for large panels: their
-// chain is not critical, and the right-looking update's 64 x 64 x 64 tiles - each reads and rewrites a 32 KB tile of the
-// panel for half a megaflop, thousands of workgroups per step - cost the trailing update that runs beside them 8 ms per
-// factorisation at N = 32768 (measured by leaving them out).  Measured: no gain (the products from L2 cost the same), so
-// this form is a tested variant, off by default; sub-panels (MGPI_PANEL_INNER) are what helped.
+// Also measured and dropped (round 2, removed in round 3): left-looking steps for large panels, the factorisation's pivot
+// recurrence on the matrix pipe (v_mfma_f64_4x4x4), the substitution on the vector pipe, the three-launch round-1 kernels.
 // `mode` splits the work for LARGE panels, where hundreds of workgroups repeating the 64 x 64 factorisation would take CU
 // time from the trailing update that runs beside the panel:
 //   mode 0  everything in one launch (every column-role workgroup factors the diagonal block itself)
@@ -232,7 +82,6 @@ extern "C" int mgpi_debug_read_trace(unsigned long long* host, unsigned* n) {
 #define PT_STAMP(k) do { } while (0)
 #define PT_FLUSH(role) do { } while (0)
 #endif
-template <bool MX, int MXF>
 __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__ A, int64_t lda, int64_t c0, int has_prev, int nfused,
                                                          int rest_cols, int64_t pivot_base, const double* __restrict__ diag0,
                                                          int* __restrict__ info, double* __restrict__ S, double ptol, int mode,
@@ -272,8 +121,7 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__
     const int64_t r0 = c0 + (int64_t)IB * b;                      // this workgroup's rows
     if (b > 0) {
         panel_load(acc, A + r0 * lda + c0, lda, w, g, c, false);
-        for (int64_t kk = c0 - (int64_t)IB * has_prev; kk < c0; kk += IB)
-            panel_gemm_nt(acc, A + (r0 + 16 * w + c) * lda + kk + 2 * g, A + (c0 + c) * lda + kk + 2 * g, lda, 0, 4);
+        if (has_prev) panel_gemm_nt(acc, A + (r0 + 16 * w + c) * lda + cp + 2 * g, A + (c0 + c) * lda + cp + 2 * g, lda, 0, 4);
     }
     if (mode == 2) {
         for (int i = tid; i < IB * IB; i += 256) (&s.Lt[0][0])[i] = F[i];
@@ -283,16 +131,10 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__
         // the diagonal block, current as of the previous step
         panel_double4_t accD[4];
         panel_load(accD, A + c0 * lda + c0, lda, w, g, c, true);
-        for (int64_t kk = c0 - (int64_t)IB * has_prev; kk < c0; kk += IB)
-            panel_gemm_nt(accD, A + (c0 + 16 * w + c) * lda + kk + 2 * g, A + (c0 + c) * lda + kk + 2 * g, lda, 0, w + 1);
+        if (has_prev) panel_gemm_nt(accD, A + (c0 + 16 * w + c) * lda + cp + 2 * g, A + (c0 + c) * lda + cp + 2 * g, lda, 0, w + 1);
         int bad = 0;
         PT_STAMP(1);
-        if constexpr (MXF != 0) {
-            panel_mx_state mxs = panel_mx_begin(s, tid, g, c);
-            potf2_acc_mx<0, MXF == 1>::run(accD, s, w, g, c, bad, b == 0 ? S : nullptr, mxs);
-        } else {
-            potf2_acc_rounds<0>::run(accD, s, w, g, c, bad, b == 0 ? S : nullptr);
-        }
+        potf2_acc_rounds<0>::run(accD, s, w, g, c, bad, b == 0 ? S : nullptr);
         PT_STAMP(2);
         if (b == 0) {
             if (tid == 0 && bad != 0) {
@@ -314,50 +156,30 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__
         }
     }
     __syncthreads();                                               // the factor's LDS images are complete
-    if constexpr (MX) {
-        panel_trsm_images(s, tid);
-        trsm_acc_mx<0>::run(acc, s, w, g, c, A + (r0 + 16 * w + c) * lda + c0);
-    } else {
-        trsm_acc_rounds<0>::run(acc, s, w, g, c, A + (r0 + 16 * w + c) * lda + c0);
-    }
+    panel_trsm_images(s, tid);
+    trsm_acc_mx<0>::run(acc, s, w, g, c, A + (r0 + 16 * w + c) * lda + c0);
     PT_STAMP(3);
     PT_FLUSH(1);
 }
 
-// Matrix-pipe forms of the two sweeps (panel_device.h).  The substitution ships in that form (MGPI_PANEL_MX=0 selects the
-// vector-pipe one): 4.9 -> 3.8 us per 64 rows alone, 20 -> 14 us beside the trailing update.  The factorisation in that form
-// (MGPI_PANEL_MX_FACTOR=1) is correct and tested but does not pay yet: 19.7 us alone against 16.4, and the same ~100 us beside
-// the trailing update - the compiler's code for it still holds ~90 vector instructions per round (register copies around the
-// tied accumulator of the small MFMA, selects), and a wave issues in order, so each of them waits like the ones it replaced.
-typedef void (*panel_step_fn)(double*, int64_t, int64_t, int, int, int, int64_t, const double*, int*, double*, double, int, double*, int64_t,
-                              int64_t, int64_t);
-static panel_step_fn panel_step_entry() {
-    static const bool mx = getenv("MGPI_PANEL_MX") ? atoi(getenv("MGPI_PANEL_MX")) != 0 : true;
-    static const int mxf = getenv("MGPI_PANEL_MX_FACTOR") ? atoi(getenv("MGPI_PANEL_MX_FACTOR")) : 0;
-    if (mxf == 1) return mx ? panel_step_kernel<true, 1> : panel_step_kernel<false, 1>;
-    if (mxf == 2) return mx ? panel_step_kernel<true, 2> : panel_step_kernel<false, 2>;
-    return mx ? panel_step_kernel<true, 0> : panel_step_kernel<false, 0>;
-}
-
 // one step: diagonal block at (c0, c0) of the matrix A (c0 absolute), `rows_below` rows below the block, the panel ends at
 // column panel_end; has_prev: the columns [c0 - 64, c0) of this panel were solved by the previous step and still have to be
-// applied to everything right of them (left: has_prev earlier blocks of the panel are applied to this step's columns only, by the
-// column-role workgroups).  split: two launches (diagonal block, then the rows) instead of one
+// applied to everything right of them.  split: two launches (diagonal block, then the rows) instead of one
 static int launch_panel_step(mgpi_ctx* ctx, double* A, int64_t lda, int64_t c0, int has_prev, int64_t rows_below, int64_t panel_end,
-                             int64_t pivot_base, const double* diag0, double* S, bool split, bool left = false) {
+                             int64_t pivot_base, const double* diag0, double* S, bool split) {
     const int nfused = (int)(1 + rows_below / IB);
-    const int rest_cols = (has_prev && !left) ? (int)((panel_end - c0 - IB) / IB) : 0;
+    const int rest_cols = has_prev ? (int)((panel_end - c0 - IB) / IB) : 0;
     int64_t nrest = 0;
     for (int tj = 0; tj < rest_cols; ++tj) nrest += nfused - 1 - tj;       // tiles on/below the diagonal, rows >= c0 + 64
     double* F = ctx->d_scal + 64;                                          // 64 x 64 + 64 doubles of the ctx's scalar scratch
     if (!split) {
-        hipLaunchKernelGGL(panel_step_entry(), dim3((unsigned)(nfused + nrest)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused,
+        hipLaunchKernelGGL(panel_step_kernel, dim3((unsigned)(nfused + nrest)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused,
                            rest_cols, pivot_base, diag0, ctx->d_info, S, ctx->pivot_tol, 0, F, (int64_t)0, (int64_t)0, (int64_t)0);
     } else {
-        hipLaunchKernelGGL(panel_step_entry(), dim3(1), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused, rest_cols, pivot_base,
+        hipLaunchKernelGGL(panel_step_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused, rest_cols, pivot_base,
                            diag0, ctx->d_info, S, ctx->pivot_tol, 1, F, (int64_t)0, (int64_t)0, (int64_t)0);
         if (nfused - 1 + nrest > 0)
-            hipLaunchKernelGGL(panel_step_entry(), dim3((unsigned)(nfused - 1 + nrest)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev,
+            hipLaunchKernelGGL(panel_step_kernel, dim3((unsigned)(nfused - 1 + nrest)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev,
                                nfused, rest_cols, pivot_base, diag0, ctx->d_info, S, ctx->pivot_tol, 2, F, (int64_t)0, (int64_t)0, (int64_t)0);
     }
     MGPI_HIP_TRY(hipGetLastError());
@@ -372,15 +194,6 @@ __global__ __launch_bounds__(256) void diag_blocks_back_kernel(double* __restric
         const int i = idx >> 6, j = idx & 63;
         A[(k * IB + i) * lda + k * IB + j] = S[(k * IB + i) * IB + j];
     }
-}
-
-// the diagonal block at A, `rows` rows below it (a multiple of 64, may be 0); S: where the factored block goes
-int mgpi_launch_potf2_trsm(mgpi_ctx* ctx, double* A, int64_t lda, int64_t pivot_base, const double* diag0, int64_t rows, double* S) {
-    MGPI_REQUIRE(rows % IB == 0, "potf2_trsm: rows=%lld not a multiple of %d", (long long)rows, IB);
-    hipLaunchKernelGGL(potf2_trsm_kernel, dim3((unsigned)(1 + rows / IB)), dim3(256), 0, ctx->stream, A, lda, pivot_base, diag0,
-                       ctx->d_info, S, ctx->pivot_tol);
-    MGPI_HIP_TRY(hipGetLastError());
-    return 0;
 }
 
 // multi-rhs 64-row block solve:  B <- L_jj^-1 B  (TRANS = false)  or  L_jj^-T B  (TRANS = true).
@@ -579,7 +392,7 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
             ctx->d_diag = nullptr;
             ctx->diag_len = 0;
         }
-        // diag(K) before factoring, then a 64-wide strip for the factored diagonal blocks (potf2_trsm_kernel)
+        // diag(K) before factoring, then a 64-wide strip for the factored diagonal blocks (panel_step_kernel)
         MGPI_HIP_TRY(hipMalloc((void**)&ctx->d_diag, (size_t)pn * (1 + IB) * sizeof(double)));
         ctx->diag_len = pn;
     }
@@ -588,61 +401,18 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     MGPI_HIP_TRY(hipGetLastError());
     mgpi_prof_begin(ctx, 2);
 
-    // panel factorisation of columns [r0, r0+w), rows [r0, pn): left-looking over 64-wide inner blocks; enqueued on
-    // whatever ctx->stream currently is
-    // Right-looking inside the panel: after 64 columns are solved, ALL remaining columns of the panel are updated with
-    // them (contraction 64: four short stages, one launch) instead of updating the next 64 columns with everything
-    // solved so far (contraction up to 448: 28 stages, each waiting for its loads) right before they are factored.
-    // The gemm sits on the panel chain, so its latency is what counts: C2 potrf 10.6 -> 9.5 ms.  The panel's columns are
-    // written up to 7 times instead of once (<= 0.5 GB per panel at N = 32768), which the chain does not notice.
-    // MGPI_PANEL_RIGHT=0 restores the left-looking order (developer switch, tested).
-    static const bool panel_right = getenv("MGPI_PANEL_RIGHT") ? atoi(getenv("MGPI_PANEL_RIGHT")) != 0 : true;
-    // potf2 and the panel trsm in one launch (potf2_trsm_kernel) while at most MGPI_PANEL_FUSE_ROWS rows lie below the
-    // diagonal block: every workgroup of the fused kernel repeats the 64 x 64 factorisation, which shortens the chain
-    // when the chip has room (C2 potrf 9.6 -> 8.7 ms) but costs CU time the trailing update wants when hundreds of them
-    // run beside it (C3 with fusion everywhere: potrf 188 -> 192 ms).  MGPI_PANEL_FUSE=0 keeps them apart.
-    static const bool panel_fused = getenv("MGPI_PANEL_FUSE") ? atoi(getenv("MGPI_PANEL_FUSE")) != 0 : true;
-    static const int64_t fuse_rows = getenv("MGPI_PANEL_FUSE_ROWS") ? atoll(getenv("MGPI_PANEL_FUSE_ROWS")) : 8192;
-    // ONE launch per 64-column step (panel_step_kernel) for the panels whose first diagonal block has at most
-    // MGPI_PANEL_STEP_ROWS rows below it; MGPI_PANEL_STEP=0 keeps the round-1 kernels everywhere (developer switch, tested).
-    static const bool panel_step = getenv("MGPI_PANEL_STEP") ? atoi(getenv("MGPI_PANEL_STEP")) != 0 : true;
-    static const int64_t step_rows = getenv("MGPI_PANEL_STEP_ROWS") ? atoll(getenv("MGPI_PANEL_STEP_ROWS")) : fuse_rows;
-    // larger panels: the same kernel as two launches per step (diagonal block, then the rows); MGPI_PANEL_STEP_SPLIT=0 leaves
-    // them to the round-1 kernels
-    static const bool step_split = getenv("MGPI_PANEL_STEP_SPLIT") ? atoi(getenv("MGPI_PANEL_STEP_SPLIT")) != 0 : true;
-    // left-looking steps (see panel_step_kernel): measured equal to the right-looking form at N = 32768 (188.7 against 188.5 ms:
-    // the j products per workgroup straight from L2 cost what the update-role tiles did), so off by default; kept as a
-    // tested variant (MGPI_PANEL_LEFT_ROWS = rows below the panel above which it applies)
-    static const int64_t left_rows = getenv("MGPI_PANEL_LEFT_ROWS") ? atoll(getenv("MGPI_PANEL_LEFT_ROWS")) : ((int64_t)1 << 40);
+    // panel factorisation of columns [r0, r0+w), rows [r0, pn), enqueued on whatever ctx->stream currently is: one launch per
+    // 64-column step (panel_step_kernel), right-looking inside the panel - after 64 columns are solved ALL remaining columns
+    // of the panel are updated with them (contraction 64, deferred by one step).  Panels whose first diagonal block has more
+    // than MGPI_PANEL_STEP_ROWS rows below it run every step as two launches (diagonal block, then the rows).
+    static const int64_t step_rows = getenv("MGPI_PANEL_STEP_ROWS") ? atoll(getenv("MGPI_PANEL_STEP_ROWS")) : 8192;
     int64_t strip_first = pn / IB;                      // first 64-block whose factored diagonal block waits in the scratch strip
     auto factor_panel = [&](int64_t r0, int64_t w) -> int {
-        if (panel_step && (pn - r0 - IB <= step_rows || step_split)) {
-            const bool split = pn - r0 - IB > step_rows;
-            const bool left = pn - r0 - IB > left_rows;          // left-looking inside large panels (see panel_step_kernel)
-            for (int64_t c0 = r0; c0 < r0 + w; c0 += IB) {
-                MGPI_TRY(launch_panel_step(ctx, A, lda, c0, left ? (int)((c0 - r0) / IB) : (c0 > r0 ? 1 : 0), pn - c0 - IB, r0 + w,
-                                           pivot_base + c0, ctx->d_diag + c0, ctx->d_diag + ctx->diag_len + c0 * IB, split, left));
-                if (c0 / IB < strip_first) strip_first = c0 / IB;
-            }
-            return 0;
-        }
+        const bool split = pn - r0 - IB > step_rows;
         for (int64_t c0 = r0; c0 < r0 + w; c0 += IB) {
-            const int64_t kk = c0 - r0;
-            if (kk > 0 && !panel_right)   // A[c0:pn, c0:c0+64] -= A[c0:pn, r0:c0] * A[c0:c0+64, r0:c0]^T
-                MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, pn - c0, IB, kk, A + c0 * lda + r0, lda, A + c0 * lda + r0, lda,
-                                          A + c0 * lda + c0, lda));
-            if (panel_fused && pn - c0 - IB <= fuse_rows) {
-                MGPI_TRY(mgpi_launch_potf2_trsm(ctx, A + c0 * lda + c0, lda, pivot_base + c0, ctx->d_diag + c0, pn - c0 - IB,
-                                                ctx->d_diag + ctx->diag_len + c0 * IB));
-                if (c0 / IB < strip_first) strip_first = c0 / IB;
-            } else {
-                MGPI_TRY(mgpi_launch_potf2(ctx, A + c0 * lda + c0, lda, pivot_base + c0, ctx->d_diag + c0));
-                MGPI_TRY(mgpi_launch_trsm_rows(ctx, A + c0 * lda + c0, lda, A + (c0 + IB) * lda + c0, lda, pn - c0 - IB));
-            }
-            const int64_t c1 = c0 + IB, rest = r0 + w - c1;
-            if (panel_right && rest > 0)  // A[c1:pn, c1:r0+w] -= A[c1:pn, c0:c1] * A[c1:r0+w, c0:c1]^T
-                MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, pn - c1, rest, IB, A + c1 * lda + c0, lda, A + c1 * lda + c0, lda,
-                                          A + c1 * lda + c1, lda));
+            MGPI_TRY(launch_panel_step(ctx, A, lda, c0, c0 > r0 ? 1 : 0, pn - c0 - IB, r0 + w, pivot_base + c0, ctx->d_diag + c0,
+                                       ctx->d_diag + ctx->diag_len + c0 * IB, split));
+            if (c0 / IB < strip_first) strip_first = c0 / IB;
         }
         return 0;
     };
@@ -823,7 +593,7 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     }
     if (lookahead && panel_on_side) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
 
-    if (strip_first < pn / IB)     // the diagonal blocks factored by panel_step_kernel / potf2_trsm_kernel wait in the scratch strip
+    if (strip_first < pn / IB)     // the factored diagonal blocks wait in the scratch strip
         hipLaunchKernelGGL(diag_blocks_back_kernel, dim3((unsigned)(pn / IB - strip_first)), dim3(256), 0, ctx->stream, A, lda,
                            ctx->d_diag + ctx->diag_len, strip_first);
     mgpi_prof_end(ctx, 2);
@@ -1049,7 +819,7 @@ extern "C" int mgpi_loglikelihood_batch(mgpi_ctx* ctx, const mgpi_mat* X, const 
         const int rest_cols = has_prev ? (int)((pn - c0 - IB) / IB) : 0;
         int64_t nrest = 0;
         for (int tj = 0; tj < rest_cols; ++tj) nrest += nfused - 1 - tj;
-        hipLaunchKernelGGL(panel_step_entry(), dim3((unsigned)(nfused + nrest), (unsigned)batch), dim3(256), 0, ctx->stream, A, lda, c0,
+        hipLaunchKernelGGL(panel_step_kernel, dim3((unsigned)(nfused + nrest), (unsigned)batch), dim3(256), 0, ctx->stream, A, lda, c0,
                            has_prev, nfused, rest_cols, c0, D0 + c0, I, S + c0 * IB, ctx->pivot_tol, 0, (double*)nullptr, strideA,
                            pn * IB, pn);
     }
@@ -1642,7 +1412,6 @@ extern "C" int mgpi_potrs(mgpi_ctx* ctx, const mgpi_mat* L, const double* b, int
 // column-role workgroup per 64 rows applies the previous step's columns to its rows of the current column block
 // (deferred right-looking update), builds the LDS images of the 64 x 64 diagonal sub-block and substitutes; update-role
 // workgroups apply the previous columns to the remaining column blocks.  One launch per step instead of two.
-template <bool MX>
 __global__ __launch_bounds__(256, 2) void trsm_right_step_kernel(double* __restrict__ A, int64_t lda, int nrowblk,
                                                                  const double* __restrict__ Lk, int64_t ldl, int64_t c0, int has_prev,
                                                                  int rest_cols) {
@@ -1672,12 +1441,8 @@ __global__ __launch_bounds__(256, 2) void trsm_right_step_kernel(double* __restr
     }
     if (tid < IB) s.invd[tid] = 1.0 / Lk[(c0 + tid) * ldl + c0 + tid];
     __syncthreads();
-    if constexpr (MX) {
-        panel_trsm_images(s, tid);
-        trsm_acc_mx<0>::run(acc, s, w, g, c, A + (r0 + 16 * w + c) * lda + c0);
-    } else {
-        trsm_acc_rounds<0>::run(acc, s, w, g, c, A + (r0 + 16 * w + c) * lda + c0);
-    }
+    panel_trsm_images(s, tid);
+    trsm_acc_mx<0>::run(acc, s, w, g, c, A + (r0 + 16 * w + c) * lda + c0);
 }
 
 extern "C" int mgpi_trsm_right_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* A) {
@@ -1687,31 +1452,15 @@ extern "C" int mgpi_trsm_right_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* A
     MGPI_REQUIRE(L->rows % IB == 0 && A->prows % IB == 0, "mgpi_trsm_right_dev: dimensions must be multiples of %d", IB);
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
     const int64_t w = L->rows, m = A->prows;
-    static const bool step_kernel = getenv("MGPI_PANEL_STEP") ? atoi(getenv("MGPI_PANEL_STEP")) != 0 : true;
-    if (step_kernel && m / IB < 32768) {
-        const int nrowblk = (int)(m / IB);
-        for (int64_t c0 = 0; c0 < w; c0 += IB) {
-            const int has_prev = c0 > 0;
-            const int rest_cols = has_prev ? (int)((w - c0 - IB) / IB) : 0;
-            static const bool mx = getenv("MGPI_PANEL_MX") ? atoi(getenv("MGPI_PANEL_MX")) != 0 : true;      // as in the step kernel
-            if (mx)
-                hipLaunchKernelGGL(trsm_right_step_kernel<true>, dim3((unsigned)(nrowblk * (1 + rest_cols))), dim3(256), 0, ctx->stream, A->d,
-                                   A->ld, nrowblk, L->d, L->ld, c0, has_prev, rest_cols);
-            else
-                hipLaunchKernelGGL(trsm_right_step_kernel<false>, dim3((unsigned)(nrowblk * (1 + rest_cols))), dim3(256), 0, ctx->stream, A->d,
-                                   A->ld, nrowblk, L->d, L->ld, c0, has_prev, rest_cols);
-        }
-        MGPI_HIP_TRY(hipGetLastError());
-        return 0;
-    }
-    // right-looking over the 64-column blocks, like the panel of the factorisation: the gemm on the chain has a
-    // contraction of 64 instead of up to w - 64  (the round-1 kernels, MGPI_PANEL_STEP=0)
+    MGPI_REQUIRE(m / IB < 32768, "mgpi_trsm_right_dev: %lld rows are more than one launch covers", (long long)m);
+    const int nrowblk = (int)(m / IB);
     for (int64_t c0 = 0; c0 < w; c0 += IB) {
-        MGPI_TRY(mgpi_launch_trsm_rows(ctx, L->d + c0 * L->ld + c0, L->ld, A->d + c0, A->ld, m));
-        const int64_t c1 = c0 + IB;
-        if (c1 < w)   // A[:, c1:w] -= A[:, c0:c1] * L[c1:w, c0:c1]^T
-            MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, m, w - c1, IB, A->d + c0, A->ld, L->d + c1 * L->ld + c0, L->ld, A->d + c1, A->ld));
+        const int has_prev = c0 > 0;
+        const int rest_cols = has_prev ? (int)((w - c0 - IB) / IB) : 0;
+        hipLaunchKernelGGL(trsm_right_step_kernel, dim3((unsigned)(nrowblk * (1 + rest_cols))), dim3(256), 0, ctx->stream, A->d, A->ld,
+                           nrowblk, L->d, L->ld, c0, has_prev, rest_cols);
     }
+    MGPI_HIP_TRY(hipGetLastError());
     return 0;
 }
 

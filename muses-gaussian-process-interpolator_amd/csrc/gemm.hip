@@ -389,126 +389,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_pipe_kernel(int64_t k, const 
             for (int r = 0; r < 4; ++r) c0[(i * 16 + 4 * r) * ldc + j * 16] = -acc[i][j][r];
 }
 
-// ---- ping-pong variant: two 4-wave groups per 512-thread workgroup, one workgroup per CU ----------------------
-// Each group owns one 128x128 tile (its own LDS double buffer, its own accumulators) and runs the loop above,
-// but the groups are staggered by one barrier: every K-stage has two workgroup barriers, and between two
-// barriers one group issues its 64 MFMAs per wave while the other does everything that is NOT matrix work
-// (wait for its global loads, write the next stage to LDS).  Each SIMD hosts one wave of either group, so its
-// MFMA pipe always has exactly one wave feeding it and the LDS/global phases of one group hide under the MFMA
-// phase of the other - with two independent workgroups per CU the two fell into lockstep and stalled together
-// (measured: loop at 83-87 % of MFMA issue rate).
-template <bool AK, bool BKM, bool LOWER>
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(int64_t k, const double* __restrict__ A, int64_t lda,
-                                                         const double* __restrict__ B, int64_t ldb,
-                                                         double* __restrict__ C, int64_t ldc, int tiles_m, int tiles_n,
-                                                         int64_t ntiles) {
-    constexpr int BM = 128, BN = 128, WM = 64, WN = 64, FM = 4, FN = 4;
-    using GA = TileGeom<BM, AK>;
-    using GB = TileGeom<BN, BKM>;
-    constexpr int STAGE = GA::doubles + GB::doubles;
-    __shared__ __attribute__((aligned(16))) double lds_all[2][2 * STAGE];
-
-    const int group = threadIdx.x >> 8;          // 0: waves 0-3, 1: waves 4-7
-    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-    double* lds = lds_all[group];
-
-    const int64_t nwg = (ntiles + 1) / 2;
-    int64_t wg = blockIdx.x;
-    {
-        const int64_t q = nwg / 8, r = nwg % 8, xcd = wg % 8, loc = wg / 8;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int64_t tile = 2 * wg + group;
-    // an odd tile count leaves the very last group without a tile: it recomputes the last tile and skips the
-    // store, so that every wave runs the same straight-line loop (no predication around loads or barriers)
-    const bool live = tile < ntiles;
-    int ti, tj;
-    tile_decode<LOWER>(live ? tile : ntiles - 1, tiles_m, tiles_n, ti, tj);
-    const int64_t m0 = (int64_t)ti * BM, n0 = (int64_t)tj * BN;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int64_t nk = k / GEMM_BK;
-
-    tile_glds<AK>(A, lda, m0, 0, tid, lds);
-    tile_glds<BKM>(B, ldb, n0, 0, tid, lds + GA::doubles);
-    double4_t acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc[i][j][r] = C[(m0 + wr * WM + i * 16 + fq + 4 * r) * ldc + n0 + wc * WN + j * 16 + fr];
-    __syncthreads();                              // stage 0 visible (both groups)
-    if (group == 1) __syncthreads();              // the stagger: group 1 runs one barrier behind (pairs with B1 of group 0)
-
-    // half a stage at a time (8 ds_read_b128 = 32 VGPRs of fragments live), fenced so that hipcc keeps the
-    // order loads | reads+MFMAs | barrier | staging writes: left alone it waited for every global load right
-    // after issuing it and parked the data in scratch
-    auto compute_stage = [&](const double* __restrict__ la, const double* __restrict__ lb) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            double af[FM][2], bf[FN][2];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                frag_pair<BM, AK>(la, wr * WM + i * 16 + fr, h, fq, af[i]);
-                af[i][0] = -af[i][0];
-                af[i][1] = -af[i][1];
-            }
-#pragma unroll
-            for (int j = 0; j < FN; ++j) frag_pair<BN, BKM>(lb, wc * WN + j * 16 + fr, h, fq, bf[j]);
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][s2], bf[j][s2], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    for (int64_t kt = 0; kt + 1 < nk; ++kt) {
-        const int cur = (int)(kt & 1);
-        // ---- matrix phase of this group (the other group idles between its two barriers): the LDS-DMA loads of the
-        // next stage fly into the other buffer while the 64 MFMAs per wave run
-        tile_glds<AK>(A, lda, m0, (kt + 1) * GEMM_BK, tid, lds + (cur ^ 1) * STAGE);
-        tile_glds<BKM>(B, ldb, n0, (kt + 1) * GEMM_BK, tid, lds + (cur ^ 1) * STAGE + GA::doubles);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_stage(lds + cur * STAGE, lds + cur * STAGE + GA::doubles);
-        __syncthreads();                          // B1: every wave has waited for its own loads (vmcnt(0)) -> stage kt+1 visible
-        __syncthreads();                          // B2: hands the MFMA pipe back (the other group computes between B1 and B2)
-    }
-    {
-        const int cur = (int)((nk - 1) & 1);
-        compute_stage(lds + cur * STAGE, lds + cur * STAGE + GA::doubles);
-    }
-    if (group == 0) __syncthreads();              // matches group 1's stagger barrier: equal barrier counts
-
-    if (live) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    C[(m0 + wr * WM + i * 16 + fq + 4 * r) * ldc + n0 + wc * WN + j * 16 + fr] = acc[i][j][r];
-    }
-}
-
-template <bool AK, bool BKM, bool LOWER>
-static int launch_pp(mgpi_ctx* ctx, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, const double* B,
-                     int64_t ldb, double* C, int64_t ldc) {
-    const int64_t tm = m / 128, tn = n / 128;
-    const int64_t ntiles = LOWER ? tm * (tm + 1) / 2 : tm * tn;
-    const int64_t nwg = (ntiles + 1) / 2;
-    MGPI_REQUIRE(nwg > 0 && nwg < (int64_t)2147483647, "gemm: tile count %lld out of range", (long long)ntiles);
-    hipLaunchKernelGGL((gemm_pp_kernel<AK, BKM, LOWER>), dim3((unsigned)nwg), dim3(512), 0, ctx->stream, k, A, lda, B, ldb, C,
-                       ldc, (int)tm, (int)tn, ntiles);
-    MGPI_HIP_TRY(hipGetLastError());
-    return 0;
-}
-
 static gemm_stair no_stair() {
     gemm_stair st;
     memset(&st, 0, sizeof(st));
@@ -578,29 +458,9 @@ int mgpi_launch_syrk_merged(mgpi_ctx* ctx, int64_t t, int64_t k, const double* P
     return 0;
 }
 
-// hand-pipelined 128x128 kernel (default); MGPI_GEMM_PIPE=0 falls back to gemm_f64_kernel<128,128,...> (developer
-// switch, both forms are tested)
-static bool use_pipe() {
-    static const char* env = getenv("MGPI_GEMM_PIPE");
-    return env ? atoi(env) != 0 : true;
-}
-
-// the ping-pong kernel is a MEASURED VARIANT, off by default: strict alternation of two 4-wave groups reached
-// 53.5 TFLOP/s at n=32256 against 61.3 for two independent workgroups per CU (whose prologue/epilogue overlap
-// the other workgroup's main loop).  MGPI_GEMM_PP=1 selects it (developer switch, tested).
-static bool use_pp(int64_t ntiles) {
-    static const char* env = getenv("MGPI_GEMM_PP");
-    (void)ntiles;
-    return env ? atoi(env) != 0 : false;
-}
-#define use_pp(nt) (use_pp(nt) && !ctx->gemm_zero_c)      /* the measured variant has no C = -A B form */
-// direct-to-LDS staging for the 128x128 tiles: +4 % on the trailing update (61.3 vs 58.8 TFLOP/s at n=32256);
-// MGPI_GEMM_GLDS=0 selects the register-staged form (developer switch, both forms are tested)
-static bool use_glds() {
-    static const char* env = getenv("MGPI_GEMM_GLDS");
-    return env ? atoi(env) != 0 : true;
-}
-
+// 128 x 128 tiles: the hand-pipelined kernel for row-major A (every shape of the hot path but the backward multi-rhs solve),
+// gemm_f64_kernel with direct-to-LDS staging for k-major A.  Measured and dropped (round 1-2, removed in round 3): a ping-pong
+// kernel of two 4-wave groups per workgroup (53.5 against 61.3 TFLOP/s at n = 32256), register-staged tiles (-4 %).
 template <bool AK, bool BKM>
 static int launch_shape(mgpi_ctx* ctx, int lower_only, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda,
                         const double* B, int64_t ldb, double* C, int64_t ldc) {
@@ -613,10 +473,8 @@ static int launch_shape(mgpi_ctx* ctx, int lower_only, int64_t m, int64_t n, int
         if constexpr (!AK && !BKM)
             if (merged_cw > 0 && (int64_t)merged_cw * 128 < m && A == B && lda == ldb)
                 return mgpi_launch_syrk_merged(ctx, m, k, A, lda, C, ldc, merged_cw, reinterpret_cast<unsigned*>(ctx->d_scal + 8064));
-        if (use_pp(m / 128 * (m / 128 + 1) / 2)) return launch_pp<AK, BKM, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
-        if constexpr (!AK) if (use_pipe()) return launch_pipe<BKM, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
-        if (use_glds()) return launch_one<128, 128, AK, BKM, true, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
-        return launch_one<128, 128, AK, BKM, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
+        if constexpr (!AK) return launch_pipe<BKM, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
+        return launch_one<128, 128, AK, BKM, true, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
     }
     // Skinny updates (the next panel's block column: t x 512 with t <= 8192) give fewer 128 x 128 tiles than the chip has
     // workgroup slots (256 CUs x 2): half the CUs idle for the length of one K = 512 tile, on the chain the next panel waits
@@ -627,10 +485,8 @@ static int launch_shape(mgpi_ctx* ctx, int lower_only, int64_t m, int64_t n, int
         return launch_one<128, 64, AK, BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
     }
     if (m % 128 == 0 && n % 128 == 0) {
-        if (use_pp((m / 128) * (n / 128))) return launch_pp<AK, BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
-        if constexpr (!AK) if (use_pipe()) return launch_pipe<BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
-        if (use_glds()) return launch_one<128, 128, AK, BKM, false, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
-        return launch_one<128, 128, AK, BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
+        if constexpr (!AK) return launch_pipe<BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
+        return launch_one<128, 128, AK, BKM, false, true>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
     }
     if (m % 128 == 0) return launch_one<128, 64, AK, BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
     if (n % 128 == 0) return launch_one<64, 128, AK, BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
@@ -699,9 +555,7 @@ extern "C" int mgpi_gemm_nt_stair_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mg
     MGPI_REQUIRE(total >= 0, "mgpi_gemm_nt_stair_dev: local trailing matrix has too many tile rows (%d)", tm);
     if (total == 0) return 0;
     mgpi_prof_begin(ctx, 0);
-    int rc = use_pipe() ? launch_pipe<false, false>(ctx, m, n, k, A->d, A->ld, B->d, B->ld, C->d, C->ld, st)
-           : use_glds() ? launch_one<128, 128, false, false, false, true>(ctx, m, n, k, A->d, A->ld, B->d, B->ld, C->d, C->ld, st)
-                        : launch_one<128, 128, false, false, false, false>(ctx, m, n, k, A->d, A->ld, B->d, B->ld, C->d, C->ld, st);
+    int rc = launch_pipe<false, false>(ctx, m, n, k, A->d, A->ld, B->d, B->ld, C->d, C->ld, st);
     mgpi_prof_end(ctx, 0);
     return rc;
 }

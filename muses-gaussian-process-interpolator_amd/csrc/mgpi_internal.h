@@ -147,8 +147,6 @@ int mgpi_launch_cov_batch(mgpi_ctx* ctx, const mgpi_terms_dev* tb_dev, int d, co
                           double* out, int64_t ldo, int64_t stride, int batch);
 
 // panel pieces of the Cholesky (chol.hip)
-int mgpi_launch_potf2(mgpi_ctx* ctx, double* A, int64_t lda, int64_t pivot_base, const double* diag0);   // 64x64 in place
-int mgpi_launch_trsm_rows(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double* A, int64_t lda, int64_t rows);
 // multi-rhs 64-row block solves on B (64 x n): trans=0: L_jj^-1 B, trans=1: L_jj^-T B
 int mgpi_launch_trsm_cols(mgpi_ctx* ctx, const double* Ljj, int64_t ldl, double* B, int64_t ldb, int64_t n, int trans);
 int mgpi_launch_gemm_nn_batched(mgpi_ctx* ctx, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, int64_t sA,

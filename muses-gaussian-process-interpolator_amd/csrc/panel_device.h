@@ -4,8 +4,6 @@
 #pragma once
 #include "mgpi_internal.h"
 
-#define IB MGPI_IB
-
 // The latency-bound kernels of the panel chain share their SIMDs with two waves of the trailing update during the
 // look-ahead.  Their own instruction streams are short dependent chains; raising the wave priority lets the SIMD's
 // arbiter issue them as soon as they are ready instead of round-robin behind MFMA issues.
@@ -13,8 +11,8 @@
 
 #define IB MGPI_IB
 
-// ---- 64x64 diagonal block: unblocked Cholesky in LDS, one workgroup ------------------------------------
-// reads only the lower triangle; writes L (lower) and zeros the strict upper part of the block.
+// ---- 64x64 diagonal block: the pivot rule ---------------------------------------------------------------
+// The factorisation (potf2_acc_rounds below) reads only the lower triangle and writes L (lower).
 // info: first failing pivot (1-based, global index pivot_base + k + 1), written with atomicCAS-min semantics.
 // A pivot fails when it is not above MGPI_PIVOT_TOL * K_kk(original): zero/negative pivots (LAPACK's test) and
 // pivots that are pure rounding noise.  The second part is what makes an exactly singular K - duplicated source
@@ -29,14 +27,6 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
-template <int SRC>
-__device__ __forceinline__ double potf2_quad_bcast(double v) {
-    constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);   // quad_perm: every lane reads quad lane SRC
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-
 // 1/sqrt(d): hardware estimate + two Newton steps
 __device__ __forceinline__ double rsq_refined(double d) {
     double y = __builtin_amdgcn_rsq(d);
@@ -44,82 +34,6 @@ __device__ __forceinline__ double rsq_refined(double d) {
     y = fma(y * 0.5, fma(-d * y, y, 1.0), y);
     return y;
 }
-
-// One ROUND eliminates FOUR columns K..K+3 (all in lane part K/16) with ONE barrier: the owning parts drop their four
-// entries per row into LDS, every lane then
-//   * reads the 4 x 4 pivot block and factors it (the same arithmetic in every lane: l_ts, 1/l_tt),
-//   * forward-substitutes its own row's four entries against that block -> the row's part of L (x_r[0..3]),
-//   * does the same for the 16 rows that face its own 16 columns (x_j[0..3], from the raw entries in LDS) - redundant
-//     arithmetic instead of a second LDS round trip and barrier - and applies the rank-4 update a_r[j] -= sum_t x_r[t] x_j[t].
-// The unblocked version (round 1) paid one barrier + one LDS round trip per COLUMN: 64 x ~900 cycles = 25 us per
-// 64 x 64 block where the dependent arithmetic (one reciprocal square root per pivot) needs ~250.  The pivots d_t are
-// the same quantities as in the unblocked algorithm (up to rounding), so the acceptance rule d_t > tol K_tt is unchanged.
-template <int K>
-struct potf2_rounds {
-    static __device__ __forceinline__ void run(double (&a)[16], double (*cb)[4][IB], const double* dtol, int r, int q, int& bad) {
-        constexpr int QK = K / 16, KL = K % 16, B = (K / 4) & 1;
-        if (q == QK) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) cb[B][t][r] = (r >= K) ? a[KL + t] : 0.0;      // rows above the block contribute nothing
-        }
-        __syncthreads();
-        // pivot block (lower part): p_it = entry (K + i, K + t)
-        const double p00 = cb[B][0][K], p10 = cb[B][0][K + 1], p20 = cb[B][0][K + 2], p30 = cb[B][0][K + 3];
-        const double p11 = cb[B][1][K + 1], p21 = cb[B][1][K + 2], p31 = cb[B][1][K + 3];
-        const double p22 = cb[B][2][K + 2], p32 = cb[B][2][K + 3], p33 = cb[B][3][K + 3];
-        double c[4][16];                                             // raw entries (row 16 q + j, column K + t)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int j = 0; j < 16; j += 2) {
-                const double2 v = *reinterpret_cast<const double2*>(&cb[B][t][16 * q + j]);
-                c[t][j] = v.x;
-                c[t][j + 1] = v.y;
-            }
-        const double a0 = potf2_quad_bcast<QK>(a[KL]), a1 = potf2_quad_bcast<QK>(a[KL + 1]);
-        const double a2 = potf2_quad_bcast<QK>(a[KL + 2]), a3 = potf2_quad_bcast<QK>(a[KL + 3]);
-        // 4 x 4 Cholesky of the pivot block; a failed pivot is replaced by 1 so that nothing downstream turns into NaN
-        const bool ok0 = p00 > dtol[K];
-        const double d0 = ok0 ? p00 : 1.0, i0 = rsq_refined(d0);
-        const double l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
-        const double e1 = fma(-l10, l10, p11);
-        const bool ok1 = e1 > dtol[K + 1];
-        const double d1 = ok1 ? e1 : 1.0, i1 = rsq_refined(d1);
-        const double l21 = fma(-l20, l10, p21) * i1, l31 = fma(-l30, l10, p31) * i1;
-        const double e2 = fma(-l21, l21, fma(-l20, l20, p22));
-        const bool ok2 = e2 > dtol[K + 2];
-        const double d2 = ok2 ? e2 : 1.0, i2 = rsq_refined(d2);
-        const double l32 = fma(-l31, l21, fma(-l30, l20, p32)) * i2;
-        const double e3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, p33)));
-        const bool ok3 = e3 > dtol[K + 3];
-        const double d3 = ok3 ? e3 : 1.0, i3 = rsq_refined(d3);
-        if (bad == 0) bad = !ok0 ? K + 1 : (!ok1 ? K + 2 : (!ok2 ? K + 3 : (!ok3 ? K + 4 : 0)));
-        // this row's entries of columns K..K+3 of L: x_t = (a_t - sum_{s<t} x_s l_ts) / l_tt for rows at or below
-        // column K + t's diagonal, 0 above (for the block's own rows this reproduces l_ts and the diagonal d_t / sqrt(d_t))
-        const double x0 = (r >= K) ? a0 * i0 : 0.0;
-        const double x1 = (r >= K + 1) ? fma(-x0, l10, a1) * i1 : 0.0;
-        const double x2 = (r >= K + 2) ? fma(-x1, l21, fma(-x0, l20, a2)) * i2 : 0.0;
-        const double x3 = (r >= K + 3) ? fma(-x2, l32, fma(-x1, l31, fma(-x0, l30, a3))) * i3 : 0.0;
-        // the same for the rows that face this lane's columns, and the rank-4 update (columns left of the block see zeros)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const double y0 = c[0][j] * i0;
-            const double y1 = fma(-y0, l10, c[1][j]) * i1;
-            const double y2 = fma(-y1, l21, fma(-y0, l20, c[2][j])) * i2;
-            const double y3 = fma(-y2, l32, fma(-y1, l31, fma(-y0, l30, c[3][j]))) * i3;
-            a[j] = fma(-x3, y3, fma(-x2, y2, fma(-x1, y1, fma(-x0, y0, a[j]))));
-        }
-        // the owning part keeps the factor entries
-        if (q == QK) {
-            a[KL] = x0;
-            a[KL + 1] = x1;
-            a[KL + 2] = x2;
-            a[KL + 3] = x3;
-        }
-        (void)d0; (void)d1; (void)d2; (void)d3;
-        if constexpr (K + 4 < IB) potf2_rounds<K + 4>::run(a, cb, dtol, r, q, bad);
-    }
-};
 
 // ---- 64-wide triangular block solves ---------------------------------------------------------------------
 // Right-looking (column-sweep) substitution: once x_k is final every later unknown subtracts its coefficient
@@ -245,13 +159,6 @@ struct __attribute__((aligned(32))) panel_lds {
     // v_mfma_f64_4x4x4 - dgA[R][i][k] = (i == k) / L[K+i][K+i],  tA[R][i][k] = (k < i) * -L[K+i][K+k] / L[K+i][K+i]
     double dgA[IB / 4][4][4];
     double tA[IB / 4][4][4];
-    // matrix-pipe factorisation (potf2_acc_mx): a zero region the size of raw, and per wave the round's multipliers, negated
-    // reciprocals and pivots as A-operand images / plain vectors; the pivots of all rounds for the check at the end
-    double zeros[2][IB][4];
-    double mA[4][4][4];
-    double rdA[4][4][4];
-    double dsel[4][4];
-    double dall[IB];
 };
 
 __device__ __forceinline__ panel_double4_t panel_row4(const double (&p)[4]) {
@@ -410,50 +317,10 @@ struct potf2_acc_rounds {
     }
 };
 
-// ---- 64-row substitution  X L^T = A  in accumulator layout --------------------------------------------------------------
-// L comes from the LDS images potf2_acc_rounds left (Lt, invd).  No barrier: every wave works on its own 16 rows.
-// Round K: the four raw entries per row go through the wave's private LDS strip, lane (c, g) solves row 16 w + c's four
-// unknowns against the 4 x 4 diagonal coefficients (wave-uniform reads), keeps y_g: stores it as the final X[row][K + g]
-// and supplies -y_g as the A operand; the B operand of tile column n is Lt[K + g][16 n + c] = L[16 n + c][K + g].
-template <int K>
-struct trsm_acc_rounds {
-    static __device__ __forceinline__ void run(panel_double4_t (&acc)[4], panel_lds& s, int w, int g, int c,
-                                               double* __restrict__ outrow /* &X[(row of 16 w + c)][0] */) {
-        constexpr int QK = K / 16, KL = K % 16;
-        if (c >= KL && c < KL + 4) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s.zraw[w][g + 4 * r][c - KL] = acc[QK][r];
-        }
-        // The strip is written and read by the same wave with no barrier in between: LDS executes one wave's
-        // instructions in order, the compiler must not move the loads above the stores either (it did: lanes write
-        // single doubles, the row is read back as a whole)
-        __asm__ volatile("" ::: "memory");
-        const panel_double4_t a = panel_row4(s.zraw[w][c]);
-        const double l10 = s.Lt[K][K + 1], l20 = s.Lt[K][K + 2], l30 = s.Lt[K][K + 3];
-        const double l21 = s.Lt[K + 1][K + 2], l31 = s.Lt[K + 1][K + 3], l32 = s.Lt[K + 2][K + 3];
-        const double y0 = a[0] * s.invd[K];
-        const double y1 = fma(-y0, l10, a[1]) * s.invd[K + 1];
-        const double y2 = fma(-y1, l21, fma(-y0, l20, a[2])) * s.invd[K + 2];
-        const double y3 = fma(-y2, l32, fma(-y1, l31, fma(-y0, l30, a[3]))) * s.invd[K + 3];
-        const double yg = (g == 0) ? y0 : (g == 1) ? y1 : (g == 2) ? y2 : y3;
-        outrow[K + g] = yg;
-#ifdef PANEL_DEBUG
-        if (K == 4) {
-            double* dbg = panel_debug2 + threadIdx.x * 8;
-            dbg[0] = a[0]; dbg[1] = a[1]; dbg[2] = a[2]; dbg[3] = a[3]; dbg[4] = yg; dbg[5] = s.invd[K]; dbg[6] = l10; dbg[7] = acc[0][0];
-        }
-#endif
-        if constexpr (K + 4 < IB) {
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-                if (n >= QK) acc[n] = PANEL_MFMA(-yg, s.Lt[K + g][16 * n + c], acc[n]);
-            trsm_acc_rounds<K + 4>::run(acc, s, w, g, c, outrow);
-        }
-    }
-};
-
-// ---- the same substitution with its dependent arithmetic on the MATRIX pipe ------------------------------------------------
-// Why: beside the trailing update the vector instructions of a panel wave are starved at issue (a dependent v_fma_f64 costs
+// ---- 64-row substitution  X L^T = A  in accumulator layout, dependent arithmetic on the MATRIX pipe -----------------------
+// L comes from the LDS images potf2_acc_rounds left (Lt, invd).  No barrier inside the sweep: every wave works on its own
+// 16 rows; per round the four raw entries per row go through the wave's private LDS strip (zraw).
+// Why the matrix pipe: beside the trailing update the vector instructions of a panel wave are starved at issue (a dependent v_fma_f64 costs
 // 430 - 490 cycles there instead of 40, tools/dp_contention_probe.hip), its matrix instructions are not (a dependent
 // v_mfma_f64_4x4x4 costs 77 - 80 instead of 44 - 48).  The 4 x 4 forward substitution of a round is therefore written as
 // matrix products.  v_mfma_f64_4x4x4 multiplies, for every group of four rows (c >> 2), A (4 x 4) by B (4 x 4) with
@@ -487,7 +354,7 @@ struct trsm_acc_mx {
 #pragma unroll
             for (int r = 0; r < 4; ++r) s.zraw[w][g + 4 * r][c - KL] = acc[QK][r];
         }
-        __asm__ volatile("" ::: "memory");      // same wave writes and reads the strip: keep the order (see trsm_acc_rounds)
+        __asm__ volatile("" ::: "memory");      // the same wave writes single doubles and reads them back: LDS executes a wave's instructions in order, the compiler must keep it too
         const double a = s.zraw[w][c][g];
         const double dg = s.dgA[R][c & 3][g], t = s.tA[R][c & 3][g];
         const double y0 = PANEL_MFMA4(dg, a, 0.0);
@@ -504,154 +371,6 @@ struct trsm_acc_mx {
         }
     }
 };
-
-// ---- 64 x 64 Cholesky with the pivot recurrence and the row solves on the MATRIX pipe ---------------------------------------
-// Same rounds, same LDS exchange and barrier, same rank-4 update as potf2_acc_rounds; what moves is every dependent vector
-// instruction of a round except four reciprocal seeds.  The recurrence of the 4 x 4 pivot block is arithmetic on wave-uniform
-// scalars; a scalar s is carried as the matrix s I_4 of every four-row group - value on the lanes with (c & 3) == g, zero on
-// the others, the same lanes in the A, B and D layouts of v_mfma_f64_4x4x4 - so a product / fused multiply-add of two such
-// scalars is ONE matrix instruction.  Signs are arranged so that nothing is ever negated: the reciprocal is carried as
-// nrd = -1 / d (seed v_rcp_f64 of -d on the diagonal lanes only, one Newton step  nx <- nx + nx (1 + d nx)), the multipliers as
-// nm = p * nrd = -m, which is what the recurrence  d' = p' + nm p  and the row solves want.
-//   * pivot-block entries arrive as s I_4 straight from LDS: the diagonal lanes read the entry, the others read a zero region
-//     at the same offsets (per-lane base pointer, compile-time offsets);
-//   * lane 0 of every wave drops the six multipliers, the four reciprocals and the four pivots into small per-wave LDS images
-//     in A-operand layout; every lane then reads ITS entry of T = -Ms (strictly lower multipliers) and of diag(nrd);
-//   * row solve  M w = a  as the fixed point of  w <- a + T w  (exact after three steps), own rows and the rows that face the
-//     wave's tile columns alike; B operand of the update  nvb = diag(nrd) w, so  acc += w nvb^T  (no negation);
-//   * rows above a column's diagonal produce garbage instead of zeros in w - it only ever reaches accumulator entries that are
-//     dead (finished rows / finished columns); the STORED entries are masked as before;
-//   * the pivots are checked against their thresholds once, after the last round (wave 0, one ballot).
-struct panel_mx_state {
-    const double* pb;      // this lane's base for pivot-block reads: &raw[0][0][0] on the diagonal lanes, the zero region elsewhere
-    double one;            // I_4: 1 on the diagonal lanes
-    double ns;             // the seed register: written on the diagonal lanes only, zero elsewhere for ever
-    bool diag;
-};
-
-// MATRIX_CHAIN = false: the HYBRID - the pivot recurrence stays on the vector pipe (uniform arithmetic in every lane, the same
-// sign conventions: nrd = -1 / d, nm = -m), everything per row goes to the matrix pipe.  The recurrence is the shorter chain
-// there when the kernel runs alone (18 dependent v_fma_f64 at 40 cycles), and none of the selects, compares and EXEC-masked
-// regions the compiler makes of the vector row solves remain.
-template <int K, bool MATRIX_CHAIN>
-struct potf2_acc_mx {
-    static __device__ __forceinline__ void run(panel_double4_t (&acc)[4], panel_lds& s, int w, int g, int c, int& bad,
-                                               double* __restrict__ S, panel_mx_state& st) {
-        constexpr int QK = K / 16, KL = K % 16, B = (K / 4) & 1;
-        if (w >= QK && c >= KL && c < KL + 4) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s.raw[B][16 * w + g + 4 * r][c - KL] = acc[QK][r];
-        }
-        __syncthreads();
-        const int row = 16 * w + c;
-        const double a = s.raw[B][row][g];                       // own row, component g
-        double d0, d1, d2, d3, nrd0, nrd1, nrd2, nrd3, nm10, nm20, nm30, nm21, nm31, nm32;
-        if constexpr (MATRIX_CHAIN) {
-            // pivot block as s I_4 (lower part), raw[B][K + i][j] at offset ((B * IB + K + i) * 4 + j)
-            const double* pb = st.pb + (B * IB + K) * 4;
-            const double P00 = pb[0], P10 = pb[4], P11 = pb[5], P20 = pb[8], P21 = pb[9], P22 = pb[10];
-            const double P30 = pb[12], P31 = pb[13], P32 = pb[14], P33 = pb[15];
-            auto nrecip = [&](double d) -> double {             // -1 / d on the diagonal lanes (0 elsewhere)
-                double ns = st.ns;
-                if (st.diag) ns = __builtin_amdgcn_rcp(-d);
-                const double e = PANEL_MFMA4(d, ns, st.one);     // 1 + d ns
-                return PANEL_MFMA4(e, ns, ns);                   // ns + ns e
-            };
-            d0 = P00;
-            nrd0 = nrecip(d0);
-            nm10 = PANEL_MFMA4(P10, nrd0, 0.0); nm20 = PANEL_MFMA4(P20, nrd0, 0.0); nm30 = PANEL_MFMA4(P30, nrd0, 0.0);
-            d1 = PANEL_MFMA4(nm10, P10, P11);
-            const double q21 = PANEL_MFMA4(nm20, P10, P21), q31 = PANEL_MFMA4(nm30, P10, P31);
-            const double u22 = PANEL_MFMA4(nm20, P20, P22), u32 = PANEL_MFMA4(nm30, P20, P32), u33 = PANEL_MFMA4(nm30, P30, P33);
-            nrd1 = nrecip(d1);
-            nm21 = PANEL_MFMA4(q21, nrd1, 0.0); nm31 = PANEL_MFMA4(q31, nrd1, 0.0);
-            d2 = PANEL_MFMA4(nm21, q21, u22);
-            const double q32 = PANEL_MFMA4(nm31, q21, u32);
-            const double v33 = PANEL_MFMA4(nm31, q31, u33);
-            nrd2 = nrecip(d2);
-            nm32 = PANEL_MFMA4(q32, nrd2, 0.0);
-            d3 = PANEL_MFMA4(nm32, q32, v33);
-            nrd3 = nrecip(d3);
-        } else {
-            const double p00 = s.raw[B][K][0], p10 = s.raw[B][K + 1][0], p20 = s.raw[B][K + 2][0], p30 = s.raw[B][K + 3][0];
-            const double p11 = s.raw[B][K + 1][1], p21 = s.raw[B][K + 2][1], p31 = s.raw[B][K + 3][1];
-            const double p22 = s.raw[B][K + 2][2], p32 = s.raw[B][K + 3][2], p33 = s.raw[B][K + 3][3];
-            auto nrecip = [](double d) -> double {              // -1 / d: estimate of 1 / (-d) + one Newton step
-                const double p = __builtin_amdgcn_rcp(-d);
-                return fma(p, fma(d, p, 1.0), p);
-            };
-            d0 = p00;
-            nrd0 = nrecip(d0);
-            nm10 = p10 * nrd0; nm20 = p20 * nrd0; nm30 = p30 * nrd0;
-            d1 = fma(nm10, p10, p11);
-            nrd1 = nrecip(d1);
-            const double q21 = fma(nm20, p10, p21), q31 = fma(nm30, p10, p31);
-            nm21 = q21 * nrd1; nm31 = q31 * nrd1;
-            d2 = fma(nm21, q21, fma(nm20, p20, p22));
-            nrd2 = nrecip(d2);
-            const double q32 = fma(nm31, q21, fma(nm30, p20, p32));
-            nm32 = q32 * nrd2;
-            d3 = fma(nm32, q32, fma(nm31, q31, fma(nm30, p30, p33)));
-            nrd3 = nrecip(d3);
-        }
-        // the images: lane 0 of the wave holds every one of these scalars (it is a diagonal lane)
-        if ((threadIdx.x & 63) == 0) {
-            s.mA[w][1][0] = nm10; s.mA[w][2][0] = nm20; s.mA[w][2][1] = nm21;
-            s.mA[w][3][0] = nm30; s.mA[w][3][1] = nm31; s.mA[w][3][2] = nm32;
-            s.rdA[w][0][0] = nrd0; s.rdA[w][1][1] = nrd1; s.rdA[w][2][2] = nrd2; s.rdA[w][3][3] = nrd3;
-            s.dsel[w][0] = d0; s.dsel[w][1] = d1; s.dsel[w][2] = d2; s.dsel[w][3] = d3;
-            if (w == 0) { s.dall[K] = d0; s.dall[K + 1] = d1; s.dall[K + 2] = d2; s.dall[K + 3] = d3; }
-        }
-        __asm__ volatile("" ::: "memory");                       // the wave reads back what its lane 0 has just written (LDS is in order)
-        const double tA = s.mA[w][c & 3][g], rA = s.rdA[w][c & 3][g];
-        const double dg = s.dsel[w][g];
-        auto solve = [&](double b) -> double {                   // M w = b for the four columns of one row, component g on lane (c, g)
-            double v = PANEL_MFMA4(tA, b, b);
-            v = PANEL_MFMA4(tA, v, b);
-            return PANEL_MFMA4(tA, v, b);
-        };
-        const double wa = solve(a);
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            if (n >= QK) {                                       // unconditional matrix instruction, zero B where it does not apply
-                double nvb = 0.0;
-                if (w >= QK && n <= w) {
-                    const double wn = (n == w) ? wa : solve(s.raw[B][16 * n + c][g]);
-                    nvb = PANEL_MFMA4(rA, wn, 0.0);                                    // -w / d, component g
-                }
-                acc[n] = PANEL_MFMA(wa, nvb, acc[n]);
-            }
-        }
-        // finished entries of columns K..K+3: zeros above the diagonal and for the waves above the block
-        const double ig = rsq_refined(dg);
-        const double x = (w >= QK && row >= K + g) ? wa * ig : 0.0;
-        if (w >= QK) s.Lt[K + g][row] = x;
-        if (row == K + g) s.invd[K + g] = ig;
-        if (S != nullptr) S[(int64_t)row * IB + K + g] = x;
-        if constexpr (K + 4 < IB) {
-            potf2_acc_mx<K + 4, MATRIX_CHAIN>::run(acc, s, w, g, c, bad, S, st);
-        } else {
-            if (w == 0) {                                        // the pivots against their thresholds, once
-                const int l = threadIdx.x & 63;
-                const bool fail = !(s.dall[l] > s.dtol[l]);
-                const unsigned long long m = __ballot(fail);
-                bad = m ? (int)__ffsll((long long)m) : 0;
-            }
-        }
-    }
-};
-
-// zero region, images and per-lane state of the matrix-pipe factorisation; all 256 threads, before the first round
-__device__ __forceinline__ panel_mx_state panel_mx_begin(panel_lds& s, int tid, int g, int c) {
-    for (int e = tid; e < 2 * IB * 4; e += 256) (&s.zeros[0][0][0])[e] = 0.0;
-    for (int e = tid; e < 4 * 16; e += 256) { (&s.mA[0][0][0])[e] = 0.0; (&s.rdA[0][0][0])[e] = 0.0; }
-    panel_mx_state st;
-    st.diag = (c & 3) == g;
-    st.pb = st.diag ? &s.raw[0][0][0] : &s.zeros[0][0][0];
-    st.one = st.diag ? 1.0 : 0.0;
-    st.ns = 0.0;
-    return st;
-}
 
 // load / store one wave's tile row of a 64 x 64 block: acc[n][r] <-> X[(16 w + g + 4 r) * ld + 16 n + c]
 __device__ __forceinline__ void panel_load(panel_double4_t (&acc)[4], const double* __restrict__ X, int64_t ld, int w, int g, int c,

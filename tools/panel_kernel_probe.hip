@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256, 2) void probe_kernel(double* __restrict__ A, i
     if (mode & 1) potf2_acc_rounds<0>::run(accD, s, w, g, c, bad, S);
     __syncthreads();
     long long t2 = clock64();
-    if (mode & 2) trsm_acc_rounds<0>::run(accT, s, w, g, c, X + (int64_t)(16 * w + c) * IB);
+    if (mode & 2) { panel_trsm_images(s, tid); trsm_acc_mx<0>::run(accT, s, w, g, c, X + (int64_t)(16 * w + c) * IB); }
     long long t3 = clock64();
     if (tid == 0) { stamps[0] = t1 - t0; stamps[1] = t2 - t1; stamps[2] = t3 - t2; stamps[3] = bad; }
     if (lane == 5) stamps[4 + w] = bad;
