@@ -16,7 +16,9 @@ value = algorithmic fp64 flops per step / wall time (TFLOP/s), flops = N^3/3 (po
 (variance trsm) + 2MN (mean); kernel evaluations (exp) are NOT counted.  roofline = the dominant kernel, the
 trailing-update syrk: algorithmic flops sum_k n_k(n_k+1) nb over its launches / HIP-event time of those
 launches, recorded inside the timed region on the stream the kernel runs on; peak = 78.6 TFLOP/s (MI355X
-fp64 matrix, spec).  cpu_baseline = the numpy oracle (a port of the reference's algorithm) on a bounded
+fp64 matrix, spec).  check = what the last timed pass left in HBM, verified before anything overwrites it: the residual
+|(K+nugget) alpha - f| / |f| on 1024 sampled rows (fused device contraction) and the range of the variance; the
+script exits 3 when it fails.  cpu_baseline = the numpy oracle (a port of the reference's algorithm) on a bounded
 sample of the same recipe, host cores of this box.
 
 N>1: one process per GPU, RCCL over xGMI through the library's own C-ABI (mgpi_comm_*; no PyTorch anywhere).  The ranks
@@ -103,6 +105,17 @@ def make_workload(name):
     return x, f, xs, ell, 1.0, 1e-2
 
 
+def finish_check(resid, rows, var, mean, sigma):
+    """the `check` object of the bench line: ok = residual < 1e-10, variance within [-1e-9, 1 + 1e-12] sigma^2, everything finite"""
+    s2 = sigma * sigma
+    ok = bool(np.isfinite(resid) and resid < 1e-10 and np.all(np.isfinite(var)) and np.all(np.isfinite(mean))
+              and var.min() > -1e-9 * s2 and var.max() <= s2 * (1.0 + 1e-12))
+    return {'residual': resid, 'residual_rows': int(rows), 'var_min': float(var.min()), 'var_max': float(var.max()),
+            'prior_var': s2, 'mean_absmax': float(np.max(np.abs(mean))), 'ok': ok,
+            'what': 'outputs of the last timed pass: |(K+nugget) alpha - f|_inf / |f|_inf on sampled source rows via the fused '
+                    'device contraction; min / max of the posterior variance at the M queries'}
+
+
 def step_flops(n, m):
     return n**3 / 3.0 + 2.0 * n * n + float(n) * n * m + 2.0 * m * n
 
@@ -179,6 +192,7 @@ class GpuStep(object):
         self.ctx = mgpi.default_context()
         self.lib = self.ctx.lib
         self.n, self.m = len(x), len(xs)
+        self.x_host, self.f_host, self.sigma = np.asarray(x), np.asarray(f), float(sigma)
         k = mgpi.SquaredExponentialKernel(sigma, *ell)
         nug = mgpi.WhiteNoiseKernel(nugget_sigma)
         self.kdesc = _lib.make_terms(k.terms())
@@ -204,6 +218,19 @@ class GpuStep(object):
         c(lib.mgpi_predict_var_dev(h, self.XS.handle, self.X.handle, self.kdesc[0], self.kdesc[1], self.L.handle, 0,
                                    self.var.handle))
 
+
+    def check(self, rows=1024):
+        """what the LAST timed pass left in HBM, verified on the device: the residual |(K + nugget) alpha - f| / |f| (max norm)
+        on `rows` evenly spaced source rows through the fused contraction (kernel + nugget evaluated at the sources
+        themselves, never a stored K), and the range of the posterior variance."""
+        DM, c = self.lib_mod.DeviceMatrix, self.lib_mod.check
+        idx = np.unique(np.linspace(0, self.n - 1, min(rows, self.n)).astype(np.int64))
+        XR = DM.from_host(self.ctx, self.x_host[idx])
+        out = DM(self.ctx, len(idx), 1)
+        c(self.lib.mgpi_predict_mean_dev(self.ctx.handle, XR.handle, self.X.handle, self.sdesc[0], self.sdesc[1], self.alpha.handle,
+                                         out.handle))
+        resid = float(np.max(np.abs(out.to_host().reshape(-1) - self.f_host[idx])) / np.max(np.abs(self.f_host)))
+        return finish_check(resid, len(idx), self.var.to_host().reshape(-1), self.mean.to_host().reshape(-1), self.sigma)
 
     def run_staged(self):
         """one pass with a tic/toc pair around every stage (untimed extra of bench.py): ms per stage"""
@@ -255,6 +282,14 @@ class DistributedStep(object):
         self.mean = gp.mean(self.xs)
         self.var = gp.variance(self.xs)
 
+    def check(self, rows=1024):
+        """as GpuStep.check, with the replicated alpha the distributed solve returned (every rank computes the same numbers)"""
+        gp = self.gp
+        idx = np.unique(np.linspace(0, self.n - 1, min(rows, self.n)).astype(np.int64))
+        ka = self.be.predict_mean(gp.x[idx], gp.x, gp.solve_terms, gp.alpha)
+        resid = float(np.max(np.abs(ka - self.f[idx])) / np.max(np.abs(self.f)))
+        return finish_check(resid, len(idx), np.asarray(self.var), np.asarray(self.mean), 1.0)
+
     def fence(self):
         """every rank has arrived and its streams are drained (the contract's barrier + device synchronise)"""
         self.be.sync()
@@ -271,20 +306,34 @@ class DistributedStep(object):
         self.transport.close()
 
 
-def cpu_baseline(seed=7):
+def cpu_baseline(m=4096, seed=7, budget_s=10.0):
     """numpy oracle ("port" of the reference algorithm: pair materialisation + LU inverse + left-associated products) on
     a bounded sample of the same recipe, timed the way BASELINE.md section 3 plans it: compress(source_x, source_f) and
-    predict(target_x, source_x, alpha) separately, at N=8192 (16x16x32 grid, BASELINE.json configs[1]'s size), M=512"""
+    predict(target_x, source_x, alpha) separately, best of R, at N=8192 (16x16x32 grid, BASELINE.json configs[1]'s size)
+    with the workload's own M.  R = 3 when one compress takes under `budget_s` seconds, else 2 (the leg stays near 30 s).
+    The stage split of compress (kernel build ~ N^2 D, LU inverse ~ N^3) gives the labelled EXTRAPOLATION to N=32768,
+    where the port cannot run (three 26 GB temporaries per kernel build)."""
     from oracle import mgpi_oracle as oracle
-    n_side, m = (16, 16, 32), 512
+    n_side = (16, 16, 32)
     x, f, xs, ell = make_inputs(n_side, m, seed)
     kernel, nugget = [oracle.term_se(1.0, *ell)], [oracle.term_white(1e-2)]
-    t0 = time.perf_counter()
-    alpha = oracle.compress(kernel, nugget, x, f)
-    t_compress = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    oracle.predict(kernel, xs, x, alpha)
-    t_predict = time.perf_counter() - t0
+    runs, alpha = [], None
+    while True:
+        st = {}
+        t0 = time.perf_counter()
+        alpha = oracle.compress(kernel, nugget, x, f, timings=st)
+        st['compress'] = time.perf_counter() - t0
+        runs.append(st)
+        if len(runs) >= (3 if runs[0]['compress'] < budget_s else 2):
+            break
+    best = min(runs, key=lambda r: r['compress'])
+    t_compress = best['compress']
+    predicts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        oracle.predict(kernel, xs, x, alpha)
+        predicts.append(time.perf_counter() - t0)
+    t_predict = min(predicts)
     dt = t_compress + t_predict
     n = len(x)
     try:    # the threads numpy's BLAS actually runs (its build caps them), not just the host's core count
@@ -299,12 +348,21 @@ def cpu_baseline(seed=7):
     except OSError:
         pass
     flops = n**3 / 3.0 + 2.0 * n * n + 2.0 * m * n              # the GPU step's count for factor + solve + mean
+    # labelled extrapolation to the bench's own N (C3): kernel build ~ N^2 D (same D), LU inverse ~ N^3, predict ~ M N D
+    big = 32768
+    r = big / float(n)
+    extrap = best['x2cov'] * r**2 + best['inv'] * r**3 + (t_compress - best['x2cov'] - best['inv']) * r**2 + t_predict * r
     return {'value': flops / dt / 1e12, 'unit': 'TFLOP/s', 'cores': threads, 'host_cores': os.cpu_count(), 'cpu_model': cpu_model,
             'kind': 'port',
-            'sample': 'oracle.compress + oracle.predict (numpy pair materialisation + LU inverse) at N=%d D=3 M=%d, same recipe; '
-                      '%.1f s wall, algorithmic flops counted as for the GPU step (Cholesky count N^3/3, although the port '
-                      'inverts by LU like the reference)' % (n, m, dt),
-            'seconds': dt, 'compress_seconds': t_compress, 'predict_seconds': t_predict}
+            'sample': 'oracle.compress + oracle.predict (numpy pair materialisation + LU inverse) at N=%d D=3 M=%d, same recipe; best '
+                      'of %d compress / 3 predict runs: %.1f s; algorithmic flops counted as for the GPU step (Cholesky count '
+                      'N^3/3, although the port inverts by LU like the reference)' % (n, m, len(runs), dt),
+            'seconds': dt, 'compress_seconds': t_compress, 'predict_seconds': t_predict, 'repeats': len(runs),
+            'compress_stage_seconds': {'x2cov': best['x2cov'], 'inv': best['inv']},
+            'all_compress_seconds': [r_['compress'] for r_ in runs],
+            'extrapolated': {'N': big, 'M': m, 'seconds': extrap,
+                             'label': 'EXTRAPOLATION, not a measurement: x2cov * (N/8192)^2 + inv * (N/8192)^3 + predict * (N/8192); '
+                                      'the port cannot run at this size (pair temporaries exceed host memory)'}}
 
 
 def load_traffic(workload):
@@ -336,7 +394,8 @@ def self_launch(args):
     if args.gpus > have:
         sys.stderr.write('bench.py: --gpus %d requested but %d HIP device(s) are visible\n' % (args.gpus, have))
         return 2
-    codes = spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+    # every rank is watched: the first one that dies ends the job with its stderr, and nothing outlives the deadline
+    codes = spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus, timeout=float(os.environ.get('MGPI_LAUNCH_TIMEOUT', '1500')))
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
         sys.stderr.write('bench.py: ranks failed (rank, exit code): %s\n' % bad)
@@ -413,6 +472,8 @@ def main():
         timed = [ctx.get_profile(i) for i in range(6)]
         timed_flops = ctx.get_profile_flops(slot)
         timed_pairs = ctx.get_profile_flops(5)
+        ctx.set_profile(False)
+        check = step.check()       # the outputs of the last timed pass, before the untimed extras overwrite them
         ctx.set_lookahead(False)
         ctx.set_profile(True)
         step.run()
@@ -431,6 +492,8 @@ def main():
         potrf_ms, _ = ctx.get_profile(2)
         colupd_ms, colupd_launches = ctx.get_profile(3)
         dom_ms, dom_launches = syrk_ms, syrk_launches
+        ctx.set_profile(False)
+        check = step.check()
     ctx.set_profile(False)
 
     if rank == 0:
@@ -476,12 +539,16 @@ def main():
                                             'predict_var': float(n) * n * m / (stages['predict_var'] * 1e-3) / 1e12}
             out['predict_mean'] = {'pairs_per_s': timed_pairs / (timed[5][0] * 1e-3) if timed[5][0] > 0 else None,
                                    'ms_per_step': timed[5][0] / args.steps}
+        out['check'] = check
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline(m=min(m, 4096))
         print(json.dumps(out), flush=True)
     if distributed:
         step.fence()
         step.close()
+    if not check['ok']:
+        sys.stderr.write('bench.py: the timed outputs FAILED their check: %s\n' % json.dumps(check))
+        sys.exit(3)
 
 
 if __name__ == '__main__':

@@ -358,6 +358,54 @@ __global__ void wait_count_kernel(const unsigned* __restrict__ counter, unsigned
     atomicCAS(info, 0, -1);
 }
 
+// Can a kernel of the look-ahead stream run WHILE a kernel of the main stream is still running?  The merged trailing update
+// depends on it (its consumer starts on a count the producer publishes half-way), and there are environments where the answer
+// is no: rocprofv3 --pmc, AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING, a single hardware queue, a debug layer - there a merged
+// factorisation would stall in wait_count_kernel until its bound and then fail.  The known switches are read from the
+// environment; everything else is caught by asking the device once per context: a two-way handshake between one wave on
+// each stream, both bounded (~16 ms), which only succeeds when the two kernels are resident at the same time, whatever the
+// order a serialising tool would run them in.
+__global__ void overlap_probe_kernel(unsigned* __restrict__ mine, const unsigned* __restrict__ theirs, int* __restrict__ ok) {
+    if (threadIdx.x != 0) return;
+    __hip_atomic_store(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int guard = 0; guard < (1 << 14); ++guard) {
+        if (__hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            atomicAdd(ok, 1);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+static bool serialising_environment() {
+    for (const char* name : {"ROCPROF_COUNTER_COLLECTION", "AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING", "CUDA_LAUNCH_BLOCKING"})
+        if (const char* v = getenv(name)) if (atoi(v) != 0) return true;
+    if (const char* v = getenv("GPU_MAX_HW_QUEUES")) if (atoi(v) == 1) return true;
+    return false;
+}
+
+// 1: the two streams of ctx overlap; 0: they do not (or the question could not be asked).  Asked once per context.
+static int streams_overlap(mgpi_ctx* ctx) {
+    if (ctx->streams_overlap >= 0) return ctx->streams_overlap;
+    ctx->streams_overlap = 0;
+    if (!ctx->stream2 || serialising_environment()) return 0;
+    unsigned* flags = reinterpret_cast<unsigned*>(ctx->d_scal + 8072);     // two handshake words and the verdict
+    int* ok = reinterpret_cast<int*>(flags + 2);
+    if (hipMemsetAsync(flags, 0, 4 * sizeof(unsigned), ctx->stream) != hipSuccess) return 0;
+    if (hipEventRecord(ctx->ev_join, ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->stream2, ctx->ev_join, 0) != hipSuccess) return 0;
+    hipLaunchKernelGGL(overlap_probe_kernel, dim3(1), dim3(64), 0, ctx->stream, flags, flags + 1, ok);
+    hipLaunchKernelGGL(overlap_probe_kernel, dim3(1), dim3(64), 0, ctx->stream2, flags + 1, flags, ok);
+    int both = 0;
+    if (hipEventRecord(ctx->ev_join, ctx->stream2) != hipSuccess || hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0) != hipSuccess ||
+        hipMemcpyAsync(&both, ok, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    ctx->streams_overlap = both == 2 ? 1 : 0;
+    return ctx->streams_overlap;
+}
+
 // ---- the factorisation ----------------------------------------------------------------------------------
 // Enqueues the whole factorisation of K on ctx's streams and returns without a host synchronisation.
 //   pivot_base  global index of K's first row: a failing pivot k is reported as pivot_base + k (1-based)
@@ -478,10 +526,13 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     // (below that the chain is critical and the narrow-tile column update reaches the panel sooner); MGPI_POTRF_MERGED=0
     // keeps the separate column update everywhere (developer switch, tested).
     // Under rocprofv3 --pmc (ROCPROF_COUNTER_COLLECTION=1) a profiled kernel runs ALONE on the GPU, so one that feeds a kernel
-    // running beside it can never do so: the separate column update is used there (same arithmetic).
-    static const bool counters = getenv("ROCPROF_COUNTER_COLLECTION") && atoi(getenv("ROCPROF_COUNTER_COLLECTION")) != 0;
-    static const bool merged_on = getenv("MGPI_POTRF_MERGED") ? atoi(getenv("MGPI_POTRF_MERGED")) != 0 : !counters;
+    // running beside it can never do so: the separate column update is used there (same arithmetic) - and in every other
+    // environment in which the two streams do not overlap (streams_overlap above: known switches + a device handshake).
+    // An explicit MGPI_POTRF_MERGED=1 still forces the merged form (how the bounded wait's failure path is tested).
+    static const int merged_env = getenv("MGPI_POTRF_MERGED") ? atoi(getenv("MGPI_POTRF_MERGED")) : -1;
     static const int64_t merged_min = getenv("MGPI_MERGED_MIN") ? atoll(getenv("MGPI_MERGED_MIN")) : 12288;
+    // (the device is only asked when this matrix is large enough for a merged step to occur at all)
+    const bool merged_on = merged_env >= 0 ? merged_env != 0 : (lookahead && pn > merged_min && streams_overlap(ctx) == 1);
     unsigned* d_sync = reinterpret_cast<unsigned*>(ctx->d_scal + 8064);
     unsigned sync_target = 0;          // tiles counted so far in this factorisation: the word only grows until the next reset
     bool merged_prev = false;          // did the previous step take the merged form (the second stream then owes no event wait)
@@ -775,8 +826,14 @@ extern "C" int mgpi_loglikelihood_batch(mgpi_ctx* ctx, const mgpi_mat* X, const 
                 double* dq = ctx->d_scal + 3;
                 hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, ctx->stream, a->d, n, dq);
                 double* land = ctx->h_pinned ? (double*)ctx->h_pinned : &q;
-                MGPI_HIP_TRY(hipMemcpyAsync(land, dq, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-                MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
+                hipError_t e = hipGetLastError();                 // a HIP error must not skip the two frees below
+                if (e == hipSuccess) e = hipMemcpyAsync(land, dq, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) {
+                    mgpi_set_error("mgpi_loglikelihood_batch: %s (sequential path, member %d)", hipGetErrorString(e), b);
+                    st = MGPI_ERR_HIP;
+                    break;
+                }
                 q = *land;
                 out[b] = -0.5 * q - 0.5 * logdet - 0.5 * (double)n * 1.8378770664093453;
                 if (info) info[b] = 0;
@@ -785,6 +842,26 @@ extern "C" int mgpi_loglikelihood_batch(mgpi_ctx* ctx, const mgpi_mat* X, const 
         mgpi_mat_free(K);
         mgpi_mat_free(a);
         return st;
+    }
+    // The batched form holds (pn + 64) x lda doubles per member: large walker counts are processed in chunks that fit the free
+    // device memory (at batch = 4096, pn = 4096 one block would be 558 GB) instead of failing on the allocation.
+    {
+        const size_t lda0 = (size_t)mgpi_roundup(pn, MGPI_TILE);
+        const size_t per = ((size_t)(pn + IB) * lda0 + (size_t)pn * IB + (size_t)pn) * sizeof(double) + sizeof(mgpi_terms_dev) + 64;
+        size_t free_b = 0, total_b = 0;
+        MGPI_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        size_t budget = free_b / 2 + (ctx->pool ? ctx->pool->held : 0);
+        static const size_t cap = getenv("MGPI_LL_CHUNK_BYTES") ? (size_t)atoll(getenv("MGPI_LL_CHUNK_BYTES")) : 0;   // tests: force chunking
+        if (cap > 0 && cap < budget) budget = cap;
+        int chunk = (int)(budget / per);
+        if (chunk < 1) chunk = 1;
+        if (chunk < batch) {
+            for (int b0 = 0; b0 < batch; b0 += chunk) {
+                const int cnt = batch - b0 < chunk ? batch - b0 : chunk;
+                MGPI_TRY(mgpi_loglikelihood_batch(ctx, X, f, terms + (size_t)b0 * nterms, nterms, cnt, out + b0, info ? info + b0 : nullptr));
+            }
+            return 0;
+        }
     }
     const int64_t lda = mgpi_roundup(pn, MGPI_TILE);
     const int64_t strideA = (pn + IB) * lda;

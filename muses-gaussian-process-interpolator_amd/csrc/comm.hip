@@ -43,16 +43,22 @@ static int rccl_load() {
         mgpi_set_error("librccl could not be loaded earlier in this process");
         return MGPI_ERR_COMM;
     }
-    const char* names[] = {getenv("MGPI_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    // MGPI_RCCL_LIB names THE library to use (nothing else is tried when it is set); otherwise the usual places
+    const char* forced = getenv("MGPI_RCCL_LIB");
+    const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     void* h = nullptr;
-    for (const char* n : names) {
-        if (n == nullptr || *n == 0) continue;
-        h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (h) break;
+    if (forced != nullptr && *forced != 0) {
+        h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    } else {
+        for (const char* n : names) {
+            h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
     }
     if (!h) {
         g_rccl_state = -1;
-        mgpi_set_error("dlopen(librccl.so.1) failed: %s", dlerror());
+        const char* why = dlerror();
+        mgpi_set_error("dlopen(%s) failed: %s", (forced != nullptr && *forced != 0) ? forced : "librccl.so.1", why ? why : "?");
         return MGPI_ERR_COMM;
     }
     g_rccl.handle = h;

@@ -39,7 +39,7 @@ struct mgpi_ctx {
     mgpi_prof_slot* prof;         // [MGPI_PROF_SLOTS]: 0 trailing update (lower syrk), 1 panel, 2 whole potrf, 3 next-panel
                                   // column update, 4 big update of the multi-rhs forward solve (variance), 5 fused predict mean
     int* d_info;                  // device: first failing pivot (0 = none)
-    double* d_scal;               // device scratch, 8192 doubles: [0] logdet, [1] status accumulator, [64, 64 + 64*64 + 64) panel images, [8000] barrier token, [8064] progress counter of the merged trailing update
+    double* d_scal;               // device scratch, 8192 doubles: [0] logdet, [1] status accumulator, [64, 64 + 64*64 + 64) panel images, [8000] barrier token, [8064] progress counter of the merged trailing update, [8072] stream-overlap handshake
     void* h_pinned;               // 64 KB of pinned host memory: small read-backs (status words, log-likelihood values) land here
                                   // without the staging copy a pageable destination costs (MGPI_PINNED_BYTES)
     double* d_diag;               // diag(K) before factoring (pivot threshold), grown on demand
@@ -47,6 +47,7 @@ struct mgpi_ctx {
     double* work;                 // device workspace, grown on demand
     size_t work_bytes;
     mgpi_pool* pool;              // freed matrix buffers awaiting reuse (core.hip)
+    int streams_overlap;          // -1 not asked yet; 1 / 0: kernels of stream and stream2 do / do not run side by side (chol.hip)
     double pivot_tol;             // a pivot must exceed pivot_tol * K_kk(original); 0 = LAPACK's "pivot > 0" rule
 };
 

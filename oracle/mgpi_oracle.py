@@ -99,25 +99,47 @@ def x2cov(terms, x1, x2):
     return paired_cov(terms, big1, big2).reshape((n1, n2))   # interpolators.py:293-294
 
 
-def x2cov_chunked(terms, x1, x2, rows=256):
+def x2cov_chunked(terms, x1, x2, rows=256, workers=1):
     """same values as x2cov, built ``rows`` rows of x1 at a time (memory-bounded variant for
-    N >= 16384 where the reference's temporaries no longer fit)"""
+    N >= 16384 where the reference's temporaries no longer fit).
+    workers > 1: the row chunks are evaluated by a thread pool (numpy releases the GIL inside its
+    ufuncs); every entry is computed by the same expression, so the result is bit-identical."""
     x1 = np.asarray(x1, dtype=float)
     x2 = np.asarray(x2, dtype=float)
     out = np.empty((len(x1), len(x2)), dtype=float)
-    for lo in range(0, len(x1), rows):
+
+    def chunk(lo):
         out[lo:lo + rows] = x2cov(terms, x1[lo:lo + rows], x2)
+
+    starts = range(0, len(x1), rows)
+    if workers <= 1:
+        for lo in starts:
+            chunk(lo)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=int(workers)) as pool:
+            list(pool.map(chunk, starts))
     return out
 
 #-------------------------------------------------
 # Interpolator methods
 
 
-def compress(kernel, nugget, source_x, source_f):
-    """alpha = inv(K(x,x; kernel+nugget)) @ f        mgpi/interpolators.py:72-105"""
+def compress(kernel, nugget, source_x, source_f, timings=None):
+    """alpha = inv(K(x,x; kernel+nugget)) @ f        mgpi/interpolators.py:72-105
+    timings: a dict that receives the seconds of the two stages the reference's verbose mode reports
+    (:78-102: "computing covariance", "inverting"); same arithmetic either way."""
+    import time
     terms = list(kernel) + (list(nugget) if nugget else [])   # kernel+nugget, kernels.py:54-59
+    t0 = time.perf_counter()
     cov_src_src = x2cov(terms, source_x, source_x)            # :81-84
-    return np.linalg.inv(cov_src_src) @ np.asarray(source_f, dtype=float)   # :92, :100
+    t1 = time.perf_counter()
+    inv = np.linalg.inv(cov_src_src)                          # :92
+    t2 = time.perf_counter()
+    if timings is not None:
+        timings['x2cov'] = t1 - t0
+        timings['inv'] = t2 - t1
+    return inv @ np.asarray(source_f, dtype=float)            # :100
 
 
 def predict(kernel, target_x, source_x, compressed):
@@ -160,6 +182,18 @@ def rvs_from_conditioned(mean, cov, size=1, rng=None):
     scales = np.diag(cov)**0.5
     zeros = np.zeros_like(mean, dtype=float)
     return mean + rng.multivariate_normal(zeros, cov / np.outer(scales, scales), size=size) * scales
+
+def rvs_cholesky(mean, cov, z):
+    """the same documented intent (mgpi/interpolators.py:314-324: ``mean + MVN(0, cov/outer(s,s)) * s``,
+    s = sqrt(diag cov)) with the normal deviates GIVEN: a sample of MVN(0, C) is chol(C) z, so with z (size, M)
+    the draws are  mean + (chol(cov / outer(s, s)) @ z.T).T * s.  A deterministic statement of the arithmetic the
+    product's device sampler performs (the reference's own call raises TypeError, SURVEY.md section 0, and numpy's
+    SVD-based multivariate_normal consumes its deviates differently) - jitter-free case only."""
+    mean = np.asarray(mean, dtype=float)
+    cov = np.asarray(cov, dtype=float)
+    scales = np.diag(cov)**0.5
+    chol = np.linalg.cholesky(cov / np.outer(scales, scales))
+    return mean + (chol @ np.asarray(z, dtype=float).T).T * scales
 
 #-------------------------------------------------
 # large-N helpers (used where the LU-inverse statement above cannot run: N >= 16384)

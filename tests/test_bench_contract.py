@@ -92,3 +92,59 @@ def test_unique_id_rendezvous_between_processes(tmp_path):
     procs = [subprocess.Popen([sys.executable, str(script2)], env=dict(env, RANK=str(r), WORLD_SIZE='2', MASTER_PORT='45678'))
              for r in (1, 0)]
     assert [p.wait(timeout=120) for p in procs] == [0, 0]
+
+
+def _rank_script(tmp_path, body):
+    import os
+    script = tmp_path / 'job.py'
+    script.write_text('import os, sys, time\nsys.path.insert(0, %r)\n'
+                      'from mgpi_amd.rendezvous import exchange_unique_id, rank_env\n'
+                      'rank, local, world = rank_env()\n' % os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + body)
+    return str(script)
+
+
+def _clean_env():
+    import os
+    return {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MGPI_RENDEZVOUS')}
+
+
+def test_spawn_ranks_reports_the_rank_that_died(tmp_path):
+    """one rank exits 3 at once, the others would block for ever (a collective that lost its peer): the job ends within
+    seconds, the survivors are killed, the exit codes and the dead rank's stderr come back (it used to hang)"""
+    import io
+    import time
+    from mgpi_amd import rendezvous
+    script = _rank_script(tmp_path, 'if rank == 2:\n    sys.stderr.write("rank two: device lost\\n"); sys.exit(3)\ntime.sleep(600)\n')
+    report = io.StringIO()
+    t0 = time.time()
+    codes = rendezvous.spawn_ranks([script], 3, env=_clean_env(), timeout=300, report=report)
+    assert time.time() - t0 < 60
+    assert codes[2] == 3 and codes[0] != 0 and codes[1] != 0, codes
+    text = report.getvalue()
+    assert 'rank 2 exited with code 3' in text and 'rank two: device lost' in text
+
+
+def test_spawn_ranks_deadline(tmp_path):
+    """nobody fails, nobody finishes: the deadline ends the job with non-zero codes"""
+    import io
+    from mgpi_amd import rendezvous
+    script = _rank_script(tmp_path, 'time.sleep(600)\n')
+    report = io.StringIO()
+    codes = rendezvous.spawn_ranks([script], 2, env=_clean_env(), timeout=3, report=report)
+    assert all(c != 0 for c in codes) and 'no result within' in report.getvalue()
+
+
+def test_unique_id_generations(tmp_path):
+    """two exchanges in one job (a second communicator): the second returns the SECOND id on every rank, even when a slow
+    rank 0 publishes it after the others already look for it (stale bytes made ncclCommInitRank hang)"""
+    from mgpi_amd import rendezvous
+    script = _rank_script(tmp_path,
+                          'a = exchange_unique_id(rank, world, lambda: b"A" * 128, timeout=60)\n'
+                          'if rank == 0: time.sleep(1.0)\n'
+                          'b = exchange_unique_id(rank, world, lambda: b"B" * 128, timeout=60)\n'
+                          'assert a == b"A" * 128 and b == b"B" * 128, (rank, a[:4], b[:4])\n'
+                          'open(os.path.join(%r, "gen%%d" %% rank), "w").close()\n'
+                          'while rank == 0 and not all(os.path.exists(os.path.join(%r, "gen%%d" %% r)) for r in range(world)): time.sleep(0.01)\n'
+                          % (str(tmp_path), str(tmp_path)))
+    codes = rendezvous.spawn_ranks([script], 3, env=_clean_env(), timeout=120)
+    assert codes == [0, 0, 0]

@@ -4,6 +4,10 @@
                             (the reference's own LU-inverse statement needs 77 GB of temporaries per _x2cov at
                             N=32768 and ~40 s at N=8192; the chunked oracle build has the same
                             entries bit for bit)
+  C3  N=32768 D=3           the same direct comparison at the configuration every bench number is quoted on [r3]: the
+                            oracle's K (8.6 GB, built by a thread pool in cache-sized row chunks - bit-identical
+                            entries), LAPACK Cholesky on the host cores, alpha, mean and variance at 512 fixed queries,
+                            loglikelihood
   C4  N=65536 D=4           on ONE GPU (the 8-GPU form is the driver's to launch): residual, variance bounds,
                             permutation invariance of logdet and alpha - the reference cannot run at this size
   C5  stellarcollapse-shaped table, 1e6 queries, mean + variance in 123 slabs of 8192 queries: a fixed subset of
@@ -46,6 +50,39 @@ def test_c2_direct_against_oracle():
     assert relmax(alpha, alpha_ref) < 100 * 4e5 * EPS
     assert relmax(it.predict(xs, x, alpha), mean_ref) < 1e-10
     mean, var = it.condition_diag(xs, x, f)
+    assert relmax(mean, mean_ref) < 1e-10
+    assert np.max(np.abs(var - var_ref)) / sigma**2 < 1e-8
+    ll = it.loglikelihood(x, f)
+    ll_ref = -0.5 * f @ alpha_ref - 0.5 * logdet_ref - 0.5 * n * np.log(2 * np.pi)
+    assert abs(ll - ll_ref) < 1e-10 * abs(ll_ref)
+
+
+def test_c3_direct_against_oracle():
+    """the headline configuration (bench.py's default workload), directly: mgpi/interpolators.py:136-204, :331-343 restated
+    by the oracle's chunked kernel build + LAPACK Cholesky helpers, exactly as test_c2_direct_against_oracle does at N=8192.
+    About 1-2 minutes of host time (kernel build ~20 s on 16 threads, dpotrf ~40 s)."""
+    import os
+    x, f, xs, ell, sigma, nugget_sigma = bench.make_workload('c3')
+    n = len(x)
+    assert n == 32768 and xs.shape == (4096, 3)
+    xq = xs[:512]
+    kernel, nugget = [oracle.term_se(sigma, *ell)], [oracle.term_white(nugget_sigma)]
+    workers = max(1, min(16, (os.cpu_count() or 2) - 1))
+    K = oracle.x2cov_chunked(kernel + nugget, x, x, rows=8, workers=workers)     # the reference's entries (interpolators.py:208-300)
+    L = oracle.cholesky_lower(K)
+    del K
+    alpha_ref = oracle.solve_cholesky(L, f)
+    mean_ref = oracle.x2cov_chunked(kernel, xq, x, rows=8) @ alpha_ref             # interpolators.py:117,125
+    var_ref = oracle.diag_variance_cholesky(kernel, L, xq, x, chunk=512)           # diag of interpolators.py:199
+    logdet_ref = 2.0 * np.sum(np.log(np.diag(L)))
+    del L
+
+    it = mgpi.Interpolator(mgpi.SquaredExponentialKernel(sigma, *ell), nugget=mgpi.WhiteNoiseKernel(nugget_sigma))
+    alpha = it.compress(x, f)
+    # cond(K) ~ 4e5 as at C2: the same recipe (ell = 2 spacings, sigma_n = 1e-2) on a finer grid
+    assert relmax(alpha, alpha_ref) < 100 * 4e5 * EPS
+    assert relmax(it.predict(xq, x, alpha), mean_ref) < 1e-10
+    mean, var = it.condition_diag(xq, x, f)
     assert relmax(mean, mean_ref) < 1e-10
     assert np.max(np.abs(var - var_ref)) / sigma**2 < 1e-8
     ll = it.loglikelihood(x, f)

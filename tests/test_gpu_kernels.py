@@ -241,14 +241,21 @@ def test_trtri_neg_strided_batch(ctx, w, batch, row_step, col_step):
                                  {'MGPI_PANEL_INNER': '512'}, {'MGPI_PANEL_INNER': '128', 'MGPI_PANEL_INNER_ROWS': '0'},
                                  {'MGPI_PANEL_INNER': '256', 'MGPI_PANEL_INNER_ROWS': '0', 'MGPI_MERGED_MIN': '0'},
                                  {'MGPI_MERGED_MIN': '0', 'MGPI_SUPER_MIN': '512'},
-                                 {'MGPI_COV_FAST': '0'}, {'MGPI_PREDICT_MFMA': '1'}, {'MGPI_GEMM_SKINNY_TILES': '0'}, {'MGPI_BCAST': 'rccl'}, {}],
+                                 {'MGPI_COV_FAST': '0'}, {'MGPI_PREDICT_MFMA': '1'}, {'MGPI_GEMM_SKINNY_TILES': '0'}, {'MGPI_BCAST': 'rccl'},
+                                 {'AMD_SERIALIZE_KERNEL': '3', 'MGPI_MERGED_MIN': '0', 'MGPI_SUPER_MIN': '512'},
+                                 {'HIP_LAUNCH_BLOCKING': '1', 'MGPI_MERGED_MIN': '0', 'MGPI_SUPER_MIN': '512'},
+                                 {'GPU_MAX_HW_QUEUES': '1', 'MGPI_MERGED_MIN': '0', 'MGPI_SUPER_MIN': '512'},
+                                 {'MGPI_LL_CHUNK_BYTES': '12000000'}, {}],
                          ids=lambda e: ','.join('%s=%s' % kv for kv in e.items()) or 'defaults')
 def test_developer_switch_variants(env):
     """the schedule thresholds and the few alternative forms that ship behind an environment switch (DESIGN.md section c)
     compute the same results: no look-ahead, no buffer pool, 1 / 2 panels per trailing update (with a threshold small enough
     for the two-level schedule to engage), the panel step as one launch everywhere / two launches everywhere, the separate
     column update instead of the merged trailing update, tail and sub-panel thresholds, the general kernel-term loop, the
-    MFMA form of predict-mean, 128-wide tiles for skinny updates.  (The measured losers of rounds 1-2 - ping-pong and
+    MFMA form of predict-mean, 128-wide tiles for skinny updates; environments that serialise kernels (AMD_SERIALIZE_KERNEL,
+    HIP_LAUNCH_BLOCKING, one hardware queue) with a threshold that WOULD engage the merged trailing update - the library must
+    notice and take the separate column update instead of stalling in its bounded wait; a log-likelihood batch split into
+    chunks.  (The measured losers of rounds 1-2 - ping-pong and
     register-staged gemm, round-1 panel kernels, left-looking steps, matrix-pipe factorisation - are gone, round 3.)"""
     import os
     import subprocess

@@ -293,6 +293,33 @@ def test_rvs_statistics_and_shapes():
     assert d2.shape == (10, 5) and np.all(np.isfinite(d2)) and np.max(np.abs(d2 - f[:5])) < 1e-3
 
 
+def test_rvs_arithmetic_against_the_restated_intent():
+    """deterministic check of rvs [r3]: the same standard-normal deviates z through the oracle's restatement of the
+    reference's documented intent, mean + (chol(cov / outer(s, s)) z^T)^T s  (mgpi/interpolators.py:314-324), with mean
+    and cov from the ORACLE's condition().  Jitter-free case (nugget large enough for a definite conditioned covariance).
+    Tolerance 1e-10 of the largest scale: two Cholesky factors of a matrix with cond ~1e3."""
+    rng = np.random.default_rng(29)
+    x = rng.random((80, 2))
+    f = np.sin(3 * x[:, 0]) + x[:, 1]
+    xs = rng.random((9, 2))
+    it = mgpi.Interpolator(mgpi.SquaredExponentialKernel(1.0, 0.25, 0.3), nugget=mgpi.WhiteNoiseKernel(0.05))
+    kernel, nugget = [oracle.term_se(1.0, 0.25, 0.3)], [oracle.term_white(0.05)]
+    mean_ref, cov_ref = oracle.condition(kernel, nugget, xs, x, f)
+
+    class Fixed(object):                                   # hands the sampler a known z
+        def __init__(self, z):
+            self.z = z
+
+        def standard_normal(self, shape):
+            assert tuple(shape) == self.z.shape
+            return self.z.copy()
+    z = np.random.default_rng(5).standard_normal((7, 9))
+    got = it.rvs(xs, x, f, size=7, rng=Fixed(z))
+    want = oracle.rvs_cholesky(mean_ref, cov_ref, z)
+    assert got.shape == want.shape == (7, 9)
+    assert np.max(np.abs(got - want)) < 1e-10 * max(1.0, np.max(np.abs(want)))
+
+
 def test_kernel_call_is_the_pairwise_matrix():
     g = load_golden('toy_multiterm')
     k = product_kernel(g, 'kernel')

@@ -236,3 +236,24 @@ def test_sample_kernel_returns_the_reference_layout(monkeypatch):
     chain, logp, sampler = it.sample_kernel(np.zeros((4, 2)), np.zeros(4), fixed={'sigma': 1.0}, num_burnin=3, num_samples=5, Verbose=True)
     assert chain.shape == (5, 4, 2) and logp.shape == (5, 4)          # num_walkers defaults to 2 * num_dim = 4
     assert calls == [(3, True), (5, True)] and sampler.vectorize
+
+
+def test_rccl_load_failure_is_reported_not_fatal(tmp_path):
+    """MGPI_RCCL_LIB names the library to use; one that cannot be loaded gives MGPI_ERR_COMM (-5) with dlopen's reason
+    from every mgpi_comm_* entry that needs RCCL - no crash, no fallback to another library [r3].  Needs no GPU:
+    mgpi_comm_unique_id only loads librccl."""
+    import subprocess
+    import sys
+    code = ('import sys; sys.path.insert(0, %r)\n'
+            'import mgpi_amd as mgpi\n'
+            'from mgpi_amd.distributed import RcclTransport\n'
+            'for attempt in range(2):\n'
+            '    try:\n'
+            '        RcclTransport.new_unique_id()\n'
+            '        raise SystemExit("a unique id came out of a library that does not exist")\n'
+            '    except mgpi.MgpiError as err:\n'
+            '        assert "status -5" in str(err) and ("dlopen" in str(err) or "could not be loaded earlier" in str(err)), str(err)\n'
+            'print("COMM-ERR-OK")\n' % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, MGPI_RCCL_LIB=str(tmp_path / 'no_such_librccl.so')),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'COMM-ERR-OK' in out.stdout, out.stdout[-1000:] + out.stderr[-2000:]

@@ -71,6 +71,14 @@ ll = it.loglikelihood(x, f)
 s, logdet = np.linalg.slogdet(K)
 assert abs(ll - (-0.5 * f @ alpha - 0.5 * logdet - 0.5 * n * np.log(2 * np.pi))) < 1e-9 * abs(ll)
 assert np.all(var > 0) and np.all(var < 1.0)
+# a batch of kernel-parameter sets against one-at-a-time calls (MGPI_LL_CHUNK_BYTES makes the library split the batch)
+rows = np.array([[1.0, 0.2, 0.2, 0.2], [1.3, 0.25, 0.2, 0.3], [0.7, 0.15, 0.3, 0.2], [1.1, 0.3, 0.3, 0.3], [0.9, 0.2, 0.25, 0.2]])
+vals, piv = it.loglikelihoods(x[:700], f[:700], rows)
+for row, v in zip(rows, vals):
+    it.update(*row)
+    assert it.loglikelihood(x[:700], f[:700]) == v, ('batched loglikelihood', row)
+assert not piv.any()
+it.update(*rows[0])
 if os.environ.get('MGPI_SUPER_MIN') or os.environ.get('MGPI_TRSM_SUPER_MIN'):
     # large enough for the two-level schedule to engage with the threshold the test sets; residual check only
     n = 4600
