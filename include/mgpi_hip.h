@@ -138,6 +138,11 @@ int  mgpi_cov_matrix_dev(mgpi_ctx* ctx, const mgpi_mat* X1, const mgpi_mat* X2,
 int  mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet);
 /* solve L L^T X = B in place, B (n x nrhs) device matrix */
 int  mgpi_potrs_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* B);
+/* factor AND solve (LAPACK's dposv):  K <- L,  B <- K^-1 B,  *logdet as above.  The reference's
+ * inv(K) @ f (mgpi/interpolators.py:92-100, :179-189).  For one right-hand side (B an (n x 1) vector) the
+ * forward sweep runs beside the factorisation, so the solve costs the backward sweep only; the arithmetic
+ * is that of mgpi_potrf_dev followed by mgpi_potrs_dev.  Same return convention as mgpi_potrf_dev. */
+int  mgpi_posv_dev(mgpi_ctx* ctx, mgpi_mat* K, mgpi_mat* B, double* logdet);
 /* host convenience: b (n, nrhs) row-major host in, x out (may alias) */
 int  mgpi_potrs(mgpi_ctx* ctx, const mgpi_mat* L, const double* b, int64_t n, int nrhs, double* x);
 /* Interpolator.loglikelihood (interpolators.py:331-343) for `batch` kernel parameter sets at once, x and f resident:

@@ -83,6 +83,7 @@ _SIGNATURES = {
     'mgpi_cov_matrix_dev': (ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(KernelDesc), ctypes.c_int, ctypes.c_int, _vp]),
     'mgpi_potrf_dev': (ctypes.c_int, [_vp, _vp, c_double_p]),
     'mgpi_potrs_dev': (ctypes.c_int, [_vp, _vp, _vp]),
+    'mgpi_posv_dev': (ctypes.c_int, [_vp, _vp, _vp, c_double_p]),
     'mgpi_potrs': (ctypes.c_int, [_vp, _vp, _vp, c_int64, ctypes.c_int, _vp]),
     'mgpi_trsm_dev': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
     'mgpi_loglikelihood_batch': (ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(KernelDesc), ctypes.c_int, ctypes.c_int, _vp, _vp]),

@@ -32,9 +32,21 @@ struct mgpi_stream_join_guard {
         c->lean = 0;
         c->gemm_zero_c = 0;
         if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+        if (c->stream3) (void)hipStreamSynchronize(c->stream3);
         (void)hipStreamSynchronize(main);
     }
 };
+
+// single-rhs sweeps (defined further down); `diag` says where the 64 x 64 DIAGONAL tiles of a block are read from - during a
+// factorisation they still wait in the scratch strip (see panel_step_kernel), afterwards they are in the matrix
+struct trsv_diag_src {
+    const double* base;     // element (r, c) of the diagonal tile that starts at row/column c0 of the block: base[(c0 + r) * rs + cm * c0 + c]
+    int64_t rs;
+    int cm;
+};
+static void launch_trsv_diag(hipStream_t stream, const double* L, int64_t lda, double* v, int w, int trans, const trsv_diag_src* diag = nullptr);
+static void launch_trsv_update(hipStream_t stream, const double* L, int64_t lda, double* v, int64_t r0, int w, int64_t first,
+                               int64_t count, int trans, const double* warm = nullptr, int warm_w = 0);
 
 // ---- ONE launch per 64-column step of a panel (round 2) -----------------------------------------------------------------
 // Step j of a panel (diagonal block at row / column c0) used to be three launches on the chain the trailing update waits
@@ -412,7 +424,12 @@ static int streams_overlap(mgpi_ctx* ctx) {
 //   keep_status 0: the failing-pivot word is cleared first and sum log L_ii goes to d_scal[0] (mgpi_potrf_dev reads both)
 //               1: the failing pivot is min-accumulated into the ctx status word and sum log L_ii is ADDED to
 //                  d_scal[1] - the block-by-block factorisation of the multi-GPU driver reads them once at the end
-static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int keep_status) {
+//   fwd_rhs     nullptr, or a vector of pn doubles (zero beyond n): the FORWARD sweep L y = f of a solve runs beside the
+//               factorisation - as soon as a super-panel's columns are final, a third stream solves its diagonal blocks (64 x 64
+//               tiles from the scratch strip) and applies its columns to the rows below, in the shadow of the trailing update
+//               that runs at the same time.  On return (stream order) fwd_rhs holds y; the solve then only owes the backward
+//               sweep.  Same kernels, same arithmetic and order as trsv_pair's forward half.
+static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int keep_status, double* fwd_rhs = nullptr) {
     MGPI_REQUIRE(ctx && K, "mgpi_potrf_dev: null pointer");
     MGPI_REQUIRE(K->rows == K->cols, "mgpi_potrf_dev: matrix is %lld x %lld, not square", (long long)K->rows, (long long)K->cols);
     MGPI_REQUIRE(K->pcols >= K->prows || K->pcols >= mgpi_roundup(K->rows, IB),
@@ -517,6 +534,26 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     hipStream_t main_stream = ctx->stream;
     mgpi_stream_join_guard join_on_error{ctx, main_stream, true};
     const bool lookahead = ctx->stream2 != nullptr && !ctx->no_lookahead;
+    // forward sweep of the columns [c_begin, c_end), just factored on ctx->stream (whichever that is right now)
+    bool fwd_used = false;
+    auto forward_columns = [&](int64_t c_begin, int64_t c_end) -> int {
+        if (fwd_rhs == nullptr) return 0;
+        hipStream_t fs = (ctx->stream3 != nullptr && lookahead) ? ctx->stream3 : ctx->stream;
+        if (fs != ctx->stream) {
+            MGPI_HIP_TRY(hipEventRecord(ctx->ev_fwd, ctx->stream));
+            MGPI_HIP_TRY(hipStreamWaitEvent(fs, ctx->ev_fwd, 0));
+            fwd_used = true;
+        }
+        const double* S = ctx->d_diag + ctx->diag_len;             // factored 64 x 64 diagonal tiles, row r of the matrix at S + 64 r
+        for (int64_t b0 = c_begin; b0 < c_end; b0 += nb) {
+            const int w = (int)((c_end - b0 < nb) ? (c_end - b0) : nb);
+            const trsv_diag_src src{S + b0 * IB, IB, 0};
+            launch_trsv_diag(fs, A + b0 * lda + b0, lda, fwd_rhs + b0, w, 0, &src);
+            launch_trsv_update(fs, A, lda, fwd_rhs, b0, w, b0 + w, pn - (b0 + w), 0);
+        }
+        MGPI_HIP_TRY(hipGetLastError());
+        return 0;
+    };
     // Merged trailing update (round 2, second half).  The block column of super-panel k+1 used to be updated by a gemm of its
     // own on the second stream, beside the main stream's update of the rest: a skinny launch (24.7 ms of stream time per
     // factorisation at N = 32768 for 1.1e12 flops) that took CUs from the big one.  Now ONE launch per step updates the whole
@@ -552,6 +589,7 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     if (wc == pn && pn <= tail_rows) MGPI_TRY(factor_panel(0, pn));
     else MGPI_TRY(factor_super(0, wc, false));
     mgpi_prof_end(ctx, 1);
+    MGPI_TRY(forward_columns(0, wc));
     if (lookahead) MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
     bool panel_on_side = false;                                  // is the current super-panel the product of stream2?
     for (int64_t r0 = 0; r0 < pn;) {
@@ -571,6 +609,7 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
             mgpi_prof_begin(ctx, 1);
             MGPI_TRY(factor_panel(r1, t));
             mgpi_prof_end(ctx, 1);
+            MGPI_TRY(forward_columns(r1, r1 + t));
             break;
         }
         const int64_t w1 = super_width(r1);                  // super-panel k+1
@@ -594,6 +633,7 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
             MGPI_HIP_TRY(hipGetLastError());
             ctx->stream = ctx->stream2;
             int rc = factor_super(r1, w1, true);
+            if (rc == 0) rc = forward_columns(r1, r1 + w1);
             ctx->stream = main_stream;
             MGPI_TRY(rc);
             MGPI_HIP_TRY(hipEventRecord(ctx->ev_panel, ctx->stream2));
@@ -611,6 +651,7 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
             int rc = mgpi_launch_gemm(ctx, 0, 0, 0, t, w1, w, P, lda, P, lda, A + r1 * lda + r1, lda);
             mgpi_prof_end(ctx, 3);
             if (rc == 0) rc = factor_super(r1, w1, true);
+            if (rc == 0) rc = forward_columns(r1, r1 + w1);
             ctx->stream = main_stream;
             MGPI_TRY(rc);
             MGPI_HIP_TRY(hipEventRecord(ctx->ev_panel, ctx->stream2));
@@ -631,6 +672,7 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
             mgpi_prof_begin(ctx, 1);
             MGPI_TRY(factor_super(r1, w1, false));
             mgpi_prof_end(ctx, 1);
+            MGPI_TRY(forward_columns(r1, r1 + w1));
             if (t2 > 0) {
                 mgpi_prof_begin(ctx, 0);
                 const double* P2 = P + w1 * lda;
@@ -643,6 +685,10 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
         wc = w1;
     }
     if (lookahead && panel_on_side) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_panel, 0));
+    if (fwd_used) {                  // the forward sweep reads the strip and the panels: it joins before anything below moves them
+        MGPI_HIP_TRY(hipEventRecord(ctx->ev_fwd, ctx->stream3));
+        MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_fwd, 0));
+    }
 
     if (strip_first < pn / IB)     // the factored diagonal blocks wait in the scratch strip
         hipLaunchKernelGGL(diag_blocks_back_kernel, dim3((unsigned)(pn / IB - strip_first)), dim3(256), 0, ctx->stream, A, lda,
@@ -657,8 +703,8 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     return 0;
 }
 
-extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
-    MGPI_TRY(potrf_enqueue(ctx, K, 0, 0));
+// the status of the factorisation just enqueued: one read-back of the failing-pivot word and sum log L_ii
+static int potrf_status(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
     int info = 0;
     double ld = 0.0;
     if (ctx->h_pinned) {
@@ -686,6 +732,33 @@ extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
     }
     if (logdet) *logdet = 2.0 * ld;
     return 0;
+}
+
+extern "C" int mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
+    MGPI_TRY(potrf_enqueue(ctx, K, 0, 0));
+    return potrf_status(ctx, K, logdet);
+}
+
+static int trsv_sweeps(mgpi_ctx* ctx, const mgpi_mat* Lm, double* v, int which);
+
+// Factor and solve in one call (LAPACK's dposv):  K <- L,  B <- K^-1 B.  What compress / condition / fit do with
+// np.linalg.inv(K) @ f in the reference (mgpi/interpolators.py:92-100, :179-189).  For ONE right-hand side the forward sweep
+// L y = f runs beside the factorisation on a third stream (potrf_enqueue, fwd_rhs), so the solve costs the backward sweep
+// only; the arithmetic is that of mgpi_potrf_dev followed by mgpi_potrs_dev, operation for operation.
+extern "C" int mgpi_posv_dev(mgpi_ctx* ctx, mgpi_mat* K, mgpi_mat* B, double* logdet) {
+    MGPI_REQUIRE(ctx && K && B, "mgpi_posv_dev: null pointer");
+    MGPI_REQUIRE(B->rows == K->rows, "mgpi_posv_dev: B has %lld rows, K is %lld", (long long)B->rows, (long long)K->rows);
+    MGPI_REQUIRE(B->prows >= K->prows || B->prows >= mgpi_roundup(K->rows, IB), "mgpi_posv_dev: B row padding smaller than K's");
+    if (!(B->cols == 1 && B->ld == 1)) {
+        MGPI_TRY(mgpi_potrf_dev(ctx, K, logdet));
+        return mgpi_potrs_dev(ctx, K, B);
+    }
+    MGPI_TRY(potrf_enqueue(ctx, K, 0, 0, B->d));
+    MGPI_TRY(potrf_status(ctx, K, logdet));
+    mgpi_prof_begin(ctx, 6);
+    const int rc = trsv_sweeps(ctx, K, B->d, 2);
+    mgpi_prof_end(ctx, 6);
+    return rc;
 }
 
 // The multi-GPU driver factors one nb x nb diagonal block per block step; reading the status back after each of them
@@ -776,7 +849,6 @@ __global__ __launch_bounds__(256) void ll_finish_kernel(const double* __restrict
         out[blockIdx.x] = (info[blockIdx.x] != 0) ? -INFINITY : -0.5 * part[0][0] - part[1][0] - 0.5 * (double)n * 1.8378770664093453;
 }
 
-static int trsv_pair(mgpi_ctx* ctx, const mgpi_mat* Lm, double* v, bool fwd_only);
 
 // *out = sum_i v[i]^2, one workgroup (the quadratic form of the sequential log-likelihood path)
 __global__ __launch_bounds__(256) void sumsq_kernel(const double* __restrict__ v, int64_t n, double* __restrict__ out) {
@@ -811,17 +883,17 @@ extern "C" int mgpi_loglikelihood_batch(mgpi_ctx* ctx, const mgpi_mat* X, const 
         for (int b = 0; b < batch && st == 0; ++b) {
             double logdet = 0.0;
             st = mgpi_cov_matrix_dev(ctx, X, nullptr, terms + (size_t)b * nterms, nterms, 1, K);
-            if (st == 0) st = mgpi_potrf_dev(ctx, K, &logdet);
+            // f^T K^-1 f = |L^-1 f|^2: the forward sweep only, riding beside the factorisation (potrf_enqueue, fwd_rhs)
+            if (st == 0) st = mgpi_mat_copy(ctx, f, a);
+            if (st == 0) st = potrf_enqueue(ctx, K, 0, 0, a->d);
+            if (st == 0) st = potrf_status(ctx, K, &logdet);
             if (st > 0) {                                   // not positive definite: this member only
                 if (info) info[b] = st;
                 out[b] = -INFINITY;
                 st = 0;
                 continue;
             }
-            // f^T K^-1 f = |L^-1 f|^2: the forward sweep only, the sum of squares on the device, one scalar back
-            if (st == 0) st = mgpi_mat_copy(ctx, f, a);
-            if (st == 0) st = trsv_pair(ctx, K, a->d, true);
-            if (st == 0) {
+            if (st == 0) {                                  // the sum of squares on the device, one scalar back
                 double q = 0.0;
                 double* dq = ctx->d_scal + 3;
                 hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(256), 0, ctx->stream, a->d, n, dq);
@@ -1100,7 +1172,7 @@ extern "C" int mgpi_trsm_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* B, int 
 // lane streams its own row 16 bytes at a time (the 4 waves together consume whole 128-byte lines);
 // (b) 64-step substitution by wave 0 with the 64x64 diagonal tile in LDS and lane broadcasts by v_readlane.
 __global__ __launch_bounds__(256) void trsv_diag_fwd_kernel(const double* __restrict__ L, int64_t lda,
-                                                            double* __restrict__ y, int w) {
+                                                            double* __restrict__ y, int w, const double* __restrict__ Dg, int64_t drs, int dcm) {
     __shared__ double ys[4096];
     __shared__ double Ls[IB][IB + 1];
     __shared__ double part[4][IB];
@@ -1110,7 +1182,7 @@ __global__ __launch_bounds__(256) void trsv_diag_fwd_kernel(const double* __rest
 #pragma unroll
         for (int u = 0; u < IB * IB / 256; ++u) {   // 16 independent loads in flight
             const int idx = tid + 256 * u;
-            Ls[idx >> 6][idx & 63] = L[(int64_t)(c0 + (idx >> 6)) * lda + c0 + (idx & 63)];
+            Ls[idx >> 6][idx & 63] = Dg[(int64_t)(c0 + (idx >> 6)) * drs + dcm * c0 + (idx & 63)];
         }
         __syncthreads();
         const double* row = L + (int64_t)(c0 + lane) * lda;
@@ -1190,11 +1262,17 @@ __global__ __launch_bounds__(256) void trsv_diag_bwd_kernel(const double* __rest
 // the part solved before s, the next diagonal tile and the 64 x 64 coupling tile (into registers).  After the barrier
 // only a register-resident 64 x 64 gemv with the fresh y_s remains.  Same arithmetic, different summation order.
 // Measured (N = 32768, rocprofv3): forward 94 -> 72 us per diagonal block, backward 79 -> 52 us; potrs 13.4 -> 10.3 ms.
+// Round 3, measured and dropped: the substitution from REGISTERS (the streaming waves write the next tile as finished
+// coefficients - scaled by the pivot's reciprocal, zero where the equation does not involve the pivot - and the solver
+// loads its 64 coefficients between the barriers, so that the chain is v_readlane x 2 + v_fma per pivot).  The chain got
+// shorter, the kernels did not: forward 44.8 us per diagonal block against 43.9, backward 39.8 against 32.9 (N = 32768,
+// rocprofv3; with two or four trips of row-segment loads in flight alike) - a sub-block is bound by the streaming waves'
+// dependent global-memory round trips and the two barriers, not by the solver's 64 pivots.
 // A variant with lanes along the row and shuffle reductions for the forward partial sums (coalesced, but 16
 // accumulators x 6 shuffles after the barrier) was measured and dropped: 174 us per diagonal block.
 #define TRSV_PIPE_MAXW 1024
 __global__ __launch_bounds__(320) void trsv_diag_fwd_pipe_kernel(const double* __restrict__ L, int64_t lda,
-                                                                 double* __restrict__ y, int w) {
+                                                                 double* __restrict__ y, int w, const double* __restrict__ Dg, int64_t drs, int dcm) {
     __shared__ double ys[TRSV_PIPE_MAXW];
     __shared__ double Tt[IB][IB + 1];      // current diagonal tile, TRANSPOSED: Tt[k][r] = T[r][k]; the pad keeps the
                                            // transposing writes (lane -> first index) off a single bank
@@ -1208,7 +1286,7 @@ __global__ __launch_bounds__(320) void trsv_diag_fwd_pipe_kernel(const double* _
 #pragma unroll
         for (int u = 0; u < IB * IB / 256; ++u) {
             const int idx = st + 256 * u;
-            Tt[idx & 63][idx >> 6] = L[(int64_t)(idx >> 6) * lda + (idx & 63)];
+            Tt[idx & 63][idx >> 6] = Dg[(int64_t)(idx >> 6) * drs + (idx & 63)];
         }
     }
     __syncthreads();
@@ -1233,7 +1311,7 @@ __global__ __launch_bounds__(320) void trsv_diag_fwd_pipe_kernel(const double* _
 #pragma unroll
             for (int u = 0; u < IB * IB / 256; ++u) {          // next diagonal tile
                 const int idx = st + 256 * u;
-                tn[u] = L[(int64_t)(c1 + (idx >> 6)) * lda + c1 + (idx & 63)];
+                tn[u] = Dg[(int64_t)(c1 + (idx >> 6)) * drs + dcm * c1 + (idx & 63)];
             }
             const double* row = L + (int64_t)(c1 + lane) * lda;
 #pragma unroll
@@ -1335,13 +1413,15 @@ __global__ __launch_bounds__(320) void trsv_diag_bwd_pipe_kernel(const double* _
     for (int i = tid; i < w; i += 320) y[i] = ys[i];
 }
 
-static void launch_trsv_diag(mgpi_ctx* ctx, const double* L, int64_t lda, double* v, int w, int trans) {
+static void launch_trsv_diag(hipStream_t stream, const double* L, int64_t lda, double* v, int w, int trans, const trsv_diag_src* diag) {
+    const trsv_diag_src in_place{L, lda, 1};
+    const trsv_diag_src d = (diag != nullptr && !trans) ? *diag : in_place;
     if (w <= TRSV_PIPE_MAXW) {
-        if (trans) hipLaunchKernelGGL(trsv_diag_bwd_pipe_kernel, dim3(1), dim3(320), 0, ctx->stream, L, lda, v, w);
-        else hipLaunchKernelGGL(trsv_diag_fwd_pipe_kernel, dim3(1), dim3(320), 0, ctx->stream, L, lda, v, w);
+        if (trans) hipLaunchKernelGGL(trsv_diag_bwd_pipe_kernel, dim3(1), dim3(320), 0, stream, L, lda, v, w);
+        else hipLaunchKernelGGL(trsv_diag_fwd_pipe_kernel, dim3(1), dim3(320), 0, stream, L, lda, v, w, d.base, d.rs, d.cm);
     } else {
-        if (trans) hipLaunchKernelGGL(trsv_diag_bwd_kernel, dim3(1), dim3(256), 0, ctx->stream, L, lda, v, w);
-        else hipLaunchKernelGGL(trsv_diag_fwd_kernel, dim3(1), dim3(256), 0, ctx->stream, L, lda, v, w);
+        if (trans) hipLaunchKernelGGL(trsv_diag_bwd_kernel, dim3(1), dim3(256), 0, stream, L, lda, v, w);
+        else hipLaunchKernelGGL(trsv_diag_fwd_kernel, dim3(1), dim3(256), 0, stream, L, lda, v, w, d.base, d.rs, d.cm);
     }
 }
 
@@ -1410,7 +1490,7 @@ __global__ __launch_bounds__(256) void trsv_update_bwd_kernel(const double* __re
 }
 
 static void launch_trsv_update(hipStream_t stream, const double* L, int64_t lda, double* v, int64_t r0, int w, int64_t first,
-                               int64_t count, int trans, const double* warm = nullptr, int warm_w = 0) {
+                               int64_t count, int trans, const double* warm, int warm_w) {
     if (count <= 0) return;
     if (!trans) {    // rows [first, first + count) below the block:  v[i] -= L[i][r0:r0+w] y
         int64_t blocks = (count + 3) / 4;
@@ -1429,23 +1509,24 @@ static void launch_trsv_update(hipStream_t stream, const double* L, int64_t lda,
 // dropped: the event record/wait pairs it puts on the chain cost more than the ~15 us gemv they take off it
 // (11.4 vs 10.3 ms at N = 32768, 2.55 vs 2.15 ms at N = 8192).
 // fwd_only: stop after L y = f (what the quadratic form f^T K^-1 f = y^T y of the log-likelihood needs)
-static int trsv_pair(mgpi_ctx* ctx, const mgpi_mat* Lm, double* v, bool fwd_only) {
+// which: 1 = forward only (L y = f), 2 = backward only (L^T x = y), 3 = both
+static int trsv_sweeps(mgpi_ctx* ctx, const mgpi_mat* Lm, double* v, int which) {
     const int64_t pn = Lm->prows <= Lm->pcols ? Lm->prows : mgpi_roundup(Lm->rows, IB);
     const int64_t lda = Lm->ld;
     const int64_t nb = ctx->nb;
     const double* L = Lm->d;
     const int64_t nblk = (pn + nb - 1) / nb;
-    for (int64_t r0 = 0; r0 < pn; r0 += nb) {
+    for (int64_t r0 = 0; (which & 1) && r0 < pn; r0 += nb) {
         const int w = (int)((pn - r0 < nb) ? (pn - r0) : nb);
-        launch_trsv_diag(ctx, L + r0 * lda + r0, lda, v + r0, w, 0);
+        launch_trsv_diag(ctx->stream, L + r0 * lda + r0, lda, v + r0, w, 0);
         const int64_t r1 = r0 + w;
         const int w1 = (int)((pn - r1 < nb) ? (pn - r1) : nb);
         launch_trsv_update(ctx->stream, L, lda, v, r0, w, r1, pn - r1, 0, w1 > 0 ? L + r1 * lda + r1 : nullptr, w1);
     }
-    for (int64_t b = fwd_only ? -1 : nblk - 1; b >= 0; --b) {
+    for (int64_t b = (which & 2) ? nblk - 1 : -1; b >= 0; --b) {
         const int64_t r0 = b * nb;
         const int w = (int)((pn - r0 < nb) ? (pn - r0) : nb);
-        launch_trsv_diag(ctx, L + r0 * lda + r0, lda, v + r0, w, 1);
+        launch_trsv_diag(ctx->stream, L + r0 * lda + r0, lda, v + r0, w, 1);
         const int wp = (int)((r0 < nb) ? r0 : nb);
         launch_trsv_update(ctx->stream, L, lda, v, r0, w, 0, r0, 1, wp > 0 ? L + (r0 - wp) * lda + (r0 - wp) : nullptr, wp);
     }
@@ -1462,7 +1543,7 @@ extern "C" int mgpi_potrs_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* B) {
     MGPI_REQUIRE(B->rows == L->rows, "mgpi_potrs_dev: B has %lld rows, L is %lld", (long long)B->rows, (long long)L->rows);
     MGPI_REQUIRE(B->prows >= L->prows, "mgpi_potrs_dev: B row padding smaller than L's");
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
-    if (B->cols == 1 && B->ld == 1) return trsv_pair(ctx, L, B->d, false);
+    if (B->cols == 1 && B->ld == 1) return trsv_sweeps(ctx, L, B->d, 3);
     MGPI_REQUIRE(B->pcols % 64 == 0, "mgpi_potrs_dev: a multi-column B must be tile padded (cols > %d)", MGPI_MAX_D);
     MGPI_TRY(trsm_blocked(ctx, L, B->d, B->ld, B->pcols, 0));
     return trsm_blocked(ctx, L, B->d, B->ld, B->pcols, 1);
@@ -1548,7 +1629,7 @@ extern "C" int mgpi_trsv_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* v, int 
     MGPI_REQUIRE(L->prows % IB == 0 && L->prows <= 4096, "mgpi_trsv_dev: block of %lld rows (need a multiple of %d, <= 4096)",
                  (long long)L->prows, IB);
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
-    launch_trsv_diag(ctx, L->d, L->ld, v->d, (int)L->prows, trans);
+    launch_trsv_diag(ctx->stream, L->d, L->ld, v->d, (int)L->prows, trans);
     MGPI_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -56,6 +56,8 @@ extern "C" int mgpi_ctx_create(int device_id, int nb, mgpi_ctx** out) {
         MGPI_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
         MGPI_HIP_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi));
     }
+    MGPI_HIP_TRY(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+    MGPI_HIP_TRY(hipEventCreateWithFlags(&c->ev_fwd, hipEventDisableTiming));
     MGPI_HIP_TRY(hipEventCreateWithFlags(&c->ev_upd, hipEventDisableTiming));
     MGPI_HIP_TRY(hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming));
     MGPI_HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -167,6 +169,8 @@ extern "C" int mgpi_ctx_destroy(mgpi_ctx* ctx) {
     delete[] ctx->prof;
     (void)hipStreamSynchronize(ctx->stream2);
     (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream3) { (void)hipStreamSynchronize(ctx->stream3); (void)hipStreamDestroy(ctx->stream3); }
+    if (ctx->ev_fwd) (void)hipEventDestroy(ctx->ev_fwd);
     (void)hipEventDestroy(ctx->ev_upd);
     (void)hipEventDestroy(ctx->ev_panel);
     (void)hipEventDestroy(ctx->ev_join);

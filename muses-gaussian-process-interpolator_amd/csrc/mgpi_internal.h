@@ -19,7 +19,7 @@ struct mgpi_prof_slot {
     double flops;       // algorithmic flops of the launches recorded in this slot (set by the launcher)
 };
 
-#define MGPI_PROF_SLOTS 6
+#define MGPI_PROF_SLOTS 7
 #define MGPI_PINNED_BYTES (64 * 1024)
 struct mgpi_pool;
 
@@ -28,6 +28,8 @@ struct mgpi_ctx {
     int nb;                       // outer Cholesky block
     hipStream_t stream;           // where launchers enqueue (the main stream, except during a look-ahead panel)
     hipStream_t stream2;          // high-priority stream of the look-ahead panel factorisation
+    hipStream_t stream3;          // the forward sweep of a solve, beside the factorisation (chol.hip, potrf_enqueue)
+    hipEvent_t ev_fwd;            // panel columns final -> stream3; stream3 done -> main stream
     hipEvent_t ev_join;           // mgpi_ctx_wait: "everything queued on this ctx so far"
     hipEvent_t ev_upd, ev_panel;  // main-stream update of a step done / look-ahead stream's panel (block) done
     int no_lookahead;             // MGPI_NO_LOOKAHEAD=1 (developer switch)
@@ -37,7 +39,8 @@ struct mgpi_ctx {
     hipEvent_t ev0, ev1;          // tic/toc
     int profile;
     mgpi_prof_slot* prof;         // [MGPI_PROF_SLOTS]: 0 trailing update (lower syrk), 1 panel, 2 whole potrf, 3 next-panel
-                                  // column update, 4 big update of the multi-rhs forward solve (variance), 5 fused predict mean
+                                  // column update, 4 big update of the multi-rhs forward solve (variance), 5 fused predict mean,
+                                  // 6 backward sweep of mgpi_posv_dev (what the solve still costs after the factorisation)
     int* d_info;                  // device: first failing pivot (0 = none)
     double* d_scal;               // device scratch, 8192 doubles: [0] logdet, [1] status accumulator, [64, 64 + 64*64 + 64) panel images, [8000] barrier token, [8064] progress counter of the merged trailing update, [8072] stream-overlap handshake
     void* h_pinned;               // 64 KB of pinned host memory: small read-backs (status words, log-likelihood values) land here

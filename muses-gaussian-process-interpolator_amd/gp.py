@@ -73,7 +73,7 @@ class _Stage(object):
 class FittedGP(object):
     """x, the Cholesky factor of K(x,x; kernel+nugget) and (optionally) alpha, resident in HBM"""
 
-    def __init__(self, ctx, source_x, kernel_terms, solve_terms, stage=None):
+    def __init__(self, ctx, source_x, kernel_terms, solve_terms, stage=None, source_f=None):
         self.ctx = ctx
         self.lib = ctx.lib
         x = _points(source_x)
@@ -96,7 +96,14 @@ class FittedGP(object):
 
         stage.begin('inverting source-source covariance matrix')
         logdet = ctypes.c_double(0.0)
-        _lib.check(self.lib.mgpi_potrf_dev(ctx.handle, self.L.handle, ctypes.byref(logdet)))
+        if source_f is None:
+            _lib.check(self.lib.mgpi_potrf_dev(ctx.handle, self.L.handle, ctypes.byref(logdet)))
+        else:
+            # factor and solve in one call: the forward sweep of alpha = K^-1 f runs beside the factorisation
+            f = _lib.as_f64(source_f).reshape(-1)
+            assert len(f) == self.n, 'source_f has %d entries for %d source points' % (len(f), self.n)
+            self.alpha = _lib.DeviceMatrix.from_host(ctx, f)
+            _lib.check(self.lib.mgpi_posv_dev(ctx.handle, self.L.handle, self.alpha.handle, ctypes.byref(logdet)))
         self.logdet = logdet.value
         stage.end()
 
@@ -176,11 +183,10 @@ class Interpolator(HyperParameterSearch):
     def fit(self, source_x, source_f=None, verbose=False):
         """build + factor K(x,x; kernel+nugget) on the GPU and (if source_f is given) solve for alpha"""
         stage = _Stage(self.context, verbose)
-        gp = FittedGP(self.context, source_x, _flatten(self.kernel), _flatten(self.kernel, self.nugget), stage=stage)
+        gp = FittedGP(self.context, source_x, _flatten(self.kernel), _flatten(self.kernel, self.nugget), stage=stage, source_f=source_f)
         if source_f is not None:
-            stage.begin('compressing observations')
-            gp.solve(source_f)
-            stage.end()
+            stage.begin('compressing observations')       # the banner of interpolators.py:98; the solve rode along with the
+            stage.end()                                    # factorisation above (mgpi_posv_dev), nothing is left to do here
         return gp
 
     def _fit_checked(self, source_x, source_f, verbose):
@@ -247,13 +253,12 @@ class Interpolator(HyperParameterSearch):
                 print('    %s' % self.kernel)
             desc, count = _lib.make_terms(_flatten(self.kernel, self.nugget))
             _lib.check(ctx.lib.mgpi_cov_matrix_dev(ctx.handle, X.handle, None, desc, count, 1, L.handle))
+            _lib.check(ctx.lib.mgpi_mat_copy(ctx.handle, F.handle, a.handle))
             try:
-                _lib.check(ctx.lib.mgpi_potrf_dev(ctx.handle, L.handle, None))
+                _lib.check(ctx.lib.mgpi_posv_dev(ctx.handle, L.handle, a.handle, None))
             except _lib.NotPositiveDefinite as err:
                 raise np.linalg.LinAlgError('source-source covariance is not positive definite (pivot %d) for parameter set %d'
                                             % (err.pivot, p))
-            _lib.check(ctx.lib.mgpi_mat_copy(ctx.handle, F.handle, a.handle))
-            _lib.check(ctx.lib.mgpi_potrs_dev(ctx.handle, L.handle, a.handle))
             out[p] = a.to_host().reshape(-1)
         return out
 

@@ -102,6 +102,50 @@ def test_potrs_and_trsm(ctx, n, nrhs):
             assert relmax(dB.to_host(), solve_triangular(L, B, lower=True, trans=trans)) < 1e-10
 
 
+@pytest.mark.parametrize('n', [1, 65, 700, 1700, 5000, 16500])
+def test_posv_is_potrf_then_potrs(ctx, n):
+    """mgpi_posv_dev (factor + solve in one call, the forward sweep riding beside the factorisation on a third stream with the
+    64 x 64 diagonal tiles read from the scratch strip) gives BIT-IDENTICAL alpha, factor and logdet to mgpi_potrf_dev followed
+    by mgpi_potrs_dev - same kernels, same order [r3].  n = 16500 engages the merged trailing update and two-panel
+    super-panels, 5000 the look-ahead panels, 1700 the one-panel tail; a matrix that is not positive definite reports its
+    pivot from the fused call too; a multi-column right-hand side takes the plain path."""
+    rng = np.random.default_rng(n)
+    x = rng.random((n, 3))
+    f = np.sin(3 * x[:, 0]) + x[:, 1] * x[:, 2]
+    terms = (mgpi.SquaredExponentialKernel(1.0, 0.2, 0.2, 0.2) + mgpi.WhiteNoiseKernel(1e-2)).terms()
+    desc, count = _lib.make_terms(terms)
+    X = _lib.DeviceMatrix.from_host(ctx, x)
+    K1, K2 = _lib.DeviceMatrix(ctx, n, n, wide=True), _lib.DeviceMatrix(ctx, n, n, wide=True)
+    for K in (K1, K2):
+        _lib.check(ctx.lib.mgpi_cov_matrix_dev(ctx.handle, X.handle, None, desc, count, 1, K.handle))
+    a1, a2 = _lib.DeviceMatrix.from_host(ctx, f), _lib.DeviceMatrix.from_host(ctx, f)
+    ld1, ld2 = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    _lib.check(ctx.lib.mgpi_potrf_dev(ctx.handle, K1.handle, ctypes.byref(ld1)))
+    _lib.check(ctx.lib.mgpi_potrs_dev(ctx.handle, K1.handle, a1.handle))
+    _lib.check(ctx.lib.mgpi_posv_dev(ctx.handle, K2.handle, a2.handle, ctypes.byref(ld2)))
+    assert ld1.value == ld2.value
+    assert np.array_equal(a1.to_host(), a2.to_host())
+    if n <= 5000:
+        assert np.array_equal(np.tril(K1.to_host()), np.tril(K2.to_host()))
+        Kh = oracle.x2cov_chunked([oracle.term_se(1.0, 0.2, 0.2, 0.2), oracle.term_white(1e-2)], x, x, rows=max(1, 262144 // n))
+        assert np.max(np.abs(Kh @ a2.to_host().reshape(-1) - f)) < 1e-11 * max(1.0, np.max(np.abs(f)))
+    # several right-hand sides: factor, then the blocked multi-rhs solve
+    if n == 700:
+        B = rng.standard_normal((n, 5))
+        _lib.check(ctx.lib.mgpi_cov_matrix_dev(ctx.handle, X.handle, None, desc, count, 1, K2.handle))
+        dB = dev(ctx, B)
+        _lib.check(ctx.lib.mgpi_posv_dev(ctx.handle, K2.handle, dB.handle, None))
+        assert relmax(Kh @ dB.to_host(), B) < 1e-10
+    # not positive definite: the pivot comes back, nothing hangs on the third stream
+    if n == 1700:
+        bad = np.eye(n)
+        bad[1234, 1234] = -1.0
+        dK, db = dev(ctx, bad), _lib.DeviceMatrix.from_host(ctx, f)
+        with pytest.raises(mgpi.NotPositiveDefinite) as err:
+            _lib.check(ctx.lib.mgpi_posv_dev(ctx.handle, dK.handle, db.handle, None))
+        assert err.value.pivot == 1235
+
+
 def test_c_abi_host_entry_points(ctx):
     """the host-pointer entry points a ctypes binding at the reference's call sites would use"""
     rng = np.random.default_rng(21)
