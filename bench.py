@@ -283,6 +283,18 @@ class DistributedStep(object):
 
     def run(self):
         gp = self.gp
+        if os.environ.get('MGPI_BENCH_PHASES') == '1':      # developer switch: a host sync and a wall-clock stamp per phase (stderr)
+            t, out = time.perf_counter(), []
+            for name, fn in (('build', gp.build), ('factor', gp.factor), ('solve', lambda: gp.solve(self.f)),
+                             ('mean', lambda: setattr(self, 'mean', gp.mean(self.xs))),
+                             ('variance', lambda: setattr(self, 'var', gp.variance(self.xs)))):
+                fn()
+                self.be.sync()
+                now = time.perf_counter()
+                out.append('%s %.1f ms' % (name, (now - t) * 1e3))
+                t = now
+            sys.stderr.write('phases: ' + ', '.join(out) + '\n')
+            return
         gp.build()
         gp.factor()
         gp.solve(self.f)
@@ -435,8 +447,13 @@ def main():
     if not distributed:
         d, m = WORKLOADS[args.workload][1], WORKLOADS[args.workload][2]
         x, f, xs, ell, sigma, nugget_sigma = make_workload(args.workload)
-        step = GpuStep(x, f, xs, ell, sigma, nugget_sigma)
         name, par = args.workload.upper(), 'single GPU'
+        if os.environ.get('MGPI_BENCH_SIDE'):      # developer switch: the same recipe on another grid (A/B against the 1 x 1 driver)
+            n_side = tuple(int(v) for v in os.environ['MGPI_BENCH_SIDE'].split('x'))
+            d = len(n_side)
+            x, f, xs, ell = make_inputs(n_side, m, 3)
+            sigma, nugget_sigma, name = 1.0, 1e-2, 'custom grid %s' % os.environ['MGPI_BENCH_SIDE']
+        step = GpuStep(x, f, xs, ell, sigma, nugget_sigma)
     else:
         if not force_dist and world not in MULTI:
             sys.stderr.write('bench.py: supported GPU counts: 1, %s\n' % sorted(MULTI))

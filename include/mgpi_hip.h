@@ -191,6 +191,8 @@ int  mgpi_cov_block_dev(mgpi_ctx* ctx, const mgpi_mat* X1, int64_t n1_valid, con
                         const mgpi_kernel_desc* terms, int nterms, mgpi_mat* out);
 /* C (m x n) -= A (m x k) * B (k x n)   (row-major B: the update of the multi-rhs triangular solve) */
 int  mgpi_gemm_nn_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* B, mgpi_mat* C);
+/* C = -(A B): C is written, not read */
+int  mgpi_gemm_nn_neg_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* B, mgpi_mat* C);
 /* C -= A B^T restricted to the tiles on/below the GLOBAL diagonal of a 2-D block-cyclic matrix: C = this rank's local
  * trailing matrix starting at local block (bi0, bj0) of an nb-blocked matrix on a P x Q grid, this rank at (p, q) */
 int  mgpi_gemm_nt_stair_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* B, mgpi_mat* C, int P, int p, int Q, int q,
@@ -206,11 +208,22 @@ int  mgpi_trtri_neg_dev(mgpi_ctx* ctx, const mgpi_mat* A, int64_t r0, int64_t c0
 /* factor K in place WITHOUT reading the result back: the first failing pivot (reported as pivot_base + k, 1-based) is
  * min-accumulated in the ctx and sum log L_ii is added to a ctx accumulator; one status_read at the end of the whole
  * factorisation replaces a host round trip per block step.  status_reset clears both. */
-int  mgpi_potrf_enqueue_dev(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base);
+int  mgpi_potrf_enqueue_dev(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, const mgpi_mat* diag0);
+/* the same for a TALL block column (m x w window, m >= w, multiples of 64) whose top w x w block is the diagonal block:
+ * that block is factored and the rows below are solved against it with the fused step kernels of the single-GPU path -
+ * the panel of a block step on grids with one process row, where the whole block column is local
+ * (role: the dpotrf + dtrsm pair inside np.linalg.inv's factorisation, mgpi/interpolators.py:92,179) */
+int  mgpi_potrf_panel_enqueue_dev(mgpi_ctx* ctx, mgpi_mat* panel, int64_t pivot_base, const mgpi_mat* diag0);
+/* diag0 (both): NULL, or a device vector with the ORIGINAL diagonal entries K_ii of the rows being factored - what a pivot is
+ * measured against (pivot > tol * K_ii).  A diagonal block that earlier block steps have updated no longer shows them (the
+ * entry of a duplicated source row is rounding noise by then), so the driver keeps diag(K) from the build and hands it in. */
 int  mgpi_ctx_status_reset(mgpi_ctx* ctx);
 int  mgpi_ctx_status_read(mgpi_ctx* ctx, int64_t* pivot, double* logdiag);      /* synchronises ctx's stream */
 /* order two contexts of one device: what `signaler` has queued so far precedes what `waiter` queues from now on */
 int  mgpi_ctx_wait(mgpi_ctx* waiter, mgpi_ctx* signaler);
+/* from now on this context's launches go to its high-priority stream (the look-ahead context of the driver: its panels and
+ * broadcasts must not queue behind the main context's trailing update); call on an idle context */
+int  mgpi_ctx_prefer_high_priority(mgpi_ctx* ctx);
 /* m[i][i] = value, i < min(rows, cols) of the handle (use a view to address part of a diagonal) */
 int  mgpi_mat_fill_diag(mgpi_ctx* ctx, mgpi_mat* m, double value);
 /* y += a x, (n x 1) vectors */

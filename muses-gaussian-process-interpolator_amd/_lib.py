@@ -94,12 +94,15 @@ _SIGNATURES = {
     'mgpi_mat_wrap': (ctypes.c_int, [_vp, _vp, c_int64, c_int64, c_int64, ctypes.c_int, ctypes.POINTER(_vp)]),
     'mgpi_cov_block_dev': (ctypes.c_int, [_vp, _vp, c_int64, _vp, c_int64, ctypes.POINTER(KernelDesc), ctypes.c_int, _vp]),
     'mgpi_gemm_nn_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    'mgpi_gemm_nn_neg_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     'mgpi_gemm_nt_stair_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp] + [ctypes.c_int] * 7),
     'mgpi_trtri_neg_dev': (ctypes.c_int, [_vp, _vp, c_int64, c_int64, c_int64, c_int64, c_int64, ctypes.c_int, _vp]),
     'mgpi_trsm_right_dev': (ctypes.c_int, [_vp, _vp, _vp]),
     'mgpi_trsv_dev': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
     'mgpi_gemv_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int]),
-    'mgpi_potrf_enqueue_dev': (ctypes.c_int, [_vp, _vp, c_int64]),
+    'mgpi_ctx_prefer_high_priority': (ctypes.c_int, [_vp]),
+    'mgpi_potrf_enqueue_dev': (ctypes.c_int, [_vp, _vp, c_int64, _vp]),
+    'mgpi_potrf_panel_enqueue_dev': (ctypes.c_int, [_vp, _vp, c_int64, _vp]),
     'mgpi_ctx_status_reset': (ctypes.c_int, [_vp]),
     'mgpi_ctx_status_read': (ctypes.c_int, [_vp, ctypes.POINTER(c_int64), c_double_p]),
     'mgpi_ctx_wait': (ctypes.c_int, [_vp, _vp]),

@@ -429,18 +429,35 @@ static int streams_overlap(mgpi_ctx* ctx) {
 //               tiles from the scratch strip) and applies its columns to the rows below, in the shadow of the trailing update
 //               that runs at the same time.  On return (stream order) fwd_rhs holds y; the solve then only owes the backward
 //               sweep.  Same kernels, same arithmetic and order as trsv_pair's forward half.
-static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int keep_status, double* fwd_rhs = nullptr) {
+//   tall        0, or 1: K is a TALL block column (m x w, m >= w, both multiples of 64; a window of a rank's local block-cyclic
+//               matrix): its top w x w block is factored and the rows below are solved against it - one super-panel of the
+//               factorisation and nothing else (no trailing matrix to update).  The block column of the multi-GPU driver on grids
+//               with one process row, where the whole panel is local: the same fused step kernels as the single-GPU path.
+//   diag_ref    nullptr, or the ORIGINAL diagonal entries of the rows being factored (device, one per column factored): what a
+//               pivot is measured against.  A block that earlier block steps have already updated no longer shows them - the
+//               diagonal entry of a duplicated source row is rounding noise by then, and noise above 100 eps times noise would
+//               pass - so the multi-GPU driver hands them in (it keeps the diagonal of K from the build).
+static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int keep_status, double* fwd_rhs = nullptr, int tall = 0,
+                         const double* diag_ref = nullptr) {
     MGPI_REQUIRE(ctx && K, "mgpi_potrf_dev: null pointer");
-    MGPI_REQUIRE(K->rows == K->cols, "mgpi_potrf_dev: matrix is %lld x %lld, not square", (long long)K->rows, (long long)K->cols);
-    MGPI_REQUIRE(K->pcols >= K->prows || K->pcols >= mgpi_roundup(K->rows, IB),
-                 "mgpi_potrf_dev: matrix must be tile padded (allocate with cols > %d)", MGPI_MAX_D);
+    if (!tall) {
+        MGPI_REQUIRE(K->rows == K->cols, "mgpi_potrf_dev: matrix is %lld x %lld, not square", (long long)K->rows, (long long)K->cols);
+        MGPI_REQUIRE(K->pcols >= K->prows || K->pcols >= mgpi_roundup(K->rows, IB),
+                     "mgpi_potrf_dev: matrix must be tile padded (allocate with cols > %d)", MGPI_MAX_D);
+    } else {
+        MGPI_REQUIRE(K->prows >= K->pcols && K->prows % IB == 0 && K->pcols % IB == 0 && K->rows == K->prows && K->cols == K->pcols && fwd_rhs == nullptr,
+                     "mgpi_potrf_panel_enqueue_dev: block column is %lld x %lld (rows >= columns, both multiples of %d)",
+                     (long long)K->prows, (long long)K->pcols, IB);
+    }
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
     if (K->dinv) {                                   // inverse diagonal blocks of a previous factor
         mgpi_pool_free(ctx, K->dinv, K->dinv_bytes);
         K->dinv = nullptr;
     }
     const int64_t n = K->rows;
-    const int64_t pn = K->prows <= K->pcols ? K->prows : mgpi_roundup(n, IB);   // factored extent (multiple of 64)
+    const int64_t pn = tall ? K->prows : (K->prows <= K->pcols ? K->prows : mgpi_roundup(n, IB));   // rows of the factored extent (multiple of 64)
+    const int64_t ncols = tall ? K->pcols : pn;                                   // columns that get factored
+    const int64_t ndiag = tall ? K->pcols : n;                                    // diagonal entries that enter sum log L_ii
     const int64_t lda = K->ld;
     double* A = K->d;
     const int64_t nb = ctx->nb;
@@ -461,9 +478,13 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
         MGPI_HIP_TRY(hipMalloc((void**)&ctx->d_diag, (size_t)pn * (1 + IB) * sizeof(double)));
         ctx->diag_len = pn;
     }
-    hipLaunchKernelGGL(save_diag_kernel, dim3((unsigned)((pn + 255) / 256)), dim3(256), 0, ctx->stream, A, lda, pn,
-                       ctx->d_diag);
-    MGPI_HIP_TRY(hipGetLastError());
+    if (diag_ref != nullptr) {
+        MGPI_HIP_TRY(hipMemcpyAsync(ctx->d_diag, diag_ref, (size_t)ncols * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        hipLaunchKernelGGL(save_diag_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, ctx->stream, A, lda, ncols,
+                           ctx->d_diag);
+        MGPI_HIP_TRY(hipGetLastError());
+    }
     mgpi_prof_begin(ctx, 2);
 
     // panel factorisation of columns [r0, r0+w), rows [r0, pn), enqueued on whatever ctx->stream currently is: one launch per
@@ -585,14 +606,15 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     static const int64_t tail_rows = getenv("MGPI_TAIL_ROWS") ? atoll(getenv("MGPI_TAIL_ROWS")) : 2048;
     int64_t wc = super_width(0);
     if (pn <= tail_rows) wc = pn;                                // small matrices: one panel from the start
+    if (tall) wc = ncols;                                        // a block column: its columns are one super-panel, and that is all
     mgpi_prof_begin(ctx, 1);
-    if (wc == pn && pn <= tail_rows) MGPI_TRY(factor_panel(0, pn));
+    if (!tall && wc == pn && pn <= tail_rows) MGPI_TRY(factor_panel(0, pn));
     else MGPI_TRY(factor_super(0, wc, false));
     mgpi_prof_end(ctx, 1);
     MGPI_TRY(forward_columns(0, wc));
     if (lookahead) MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
     bool panel_on_side = false;                                  // is the current super-panel the product of stream2?
-    for (int64_t r0 = 0; r0 < pn;) {
+    for (int64_t r0 = 0; r0 < pn && !tall;) {
         const int64_t w = wc;                                 // super-panel k (already factored)
         const int64_t t = pn - r0 - w;                        // trailing size
         if (t <= 0) break;
@@ -690,15 +712,15 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
         MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_fwd, 0));
     }
 
-    if (strip_first < pn / IB)     // the factored diagonal blocks wait in the scratch strip
-        hipLaunchKernelGGL(diag_blocks_back_kernel, dim3((unsigned)(pn / IB - strip_first)), dim3(256), 0, ctx->stream, A, lda,
+    if (strip_first < ncols / IB)  // the factored diagonal blocks wait in the scratch strip
+        hipLaunchKernelGGL(diag_blocks_back_kernel, dim3((unsigned)(ncols / IB - strip_first)), dim3(256), 0, ctx->stream, A, lda,
                            ctx->d_diag + ctx->diag_len, strip_first);
     mgpi_prof_end(ctx, 2);
 
-    hipLaunchKernelGGL(logdiag_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, n, ctx->d_scal + (keep_status ? 1 : 0),
+    hipLaunchKernelGGL(logdiag_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, ndiag, ctx->d_scal + (keep_status ? 1 : 0),
                        keep_status);
     MGPI_HIP_TRY(hipGetLastError());
-    K->factored = 1;          // mgpi_potrf_dev takes it back when the status says otherwise
+    K->factored = tall ? 0 : 1;          // mgpi_potrf_dev takes it back when the status says otherwise
     join_on_error.armed = false;
     return 0;
 }
@@ -764,9 +786,30 @@ extern "C" int mgpi_posv_dev(mgpi_ctx* ctx, mgpi_mat* K, mgpi_mat* B, double* lo
 // The multi-GPU driver factors one nb x nb diagonal block per block step; reading the status back after each of them
 // would put a host round trip on the critical path of every step (round 1: 217 ms against 189 at N = 32768).  These three
 // keep the status on the device: reset once, enqueue the block factorisations, read once.
-extern "C" int mgpi_potrf_enqueue_dev(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base) {
+static int diag_ref_ok(const mgpi_mat* K, const mgpi_mat* diag0, const double** out) {
+    *out = nullptr;
+    if (diag0 == nullptr) return 0;
+    MGPI_REQUIRE(diag0->ld == 1 && diag0->prows >= K->pcols, "pivot reference: need a vector with one entry per column (%lld), got %lld",
+                 (long long)K->pcols, (long long)diag0->prows);
+    *out = diag0->d;
+    return 0;
+}
+
+extern "C" int mgpi_potrf_enqueue_dev(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, const mgpi_mat* diag0) {
+    MGPI_REQUIRE(ctx && K, "mgpi_potrf_enqueue_dev: null pointer");
     MGPI_REQUIRE(pivot_base >= 0 && pivot_base < (int64_t)2147483647 - 70000, "mgpi_potrf_enqueue_dev: pivot_base out of range");
-    return potrf_enqueue(ctx, K, pivot_base, 1);
+    const double* ref = nullptr;
+    MGPI_TRY(diag_ref_ok(K, diag0, &ref));
+    return potrf_enqueue(ctx, K, pivot_base, 1, nullptr, 0, ref);
+}
+
+// the tall form (see potrf_enqueue): panel = an (m x w) block column whose top w x w block is the diagonal block
+extern "C" int mgpi_potrf_panel_enqueue_dev(mgpi_ctx* ctx, mgpi_mat* panel, int64_t pivot_base, const mgpi_mat* diag0) {
+    MGPI_REQUIRE(ctx && panel, "mgpi_potrf_panel_enqueue_dev: null pointer");
+    MGPI_REQUIRE(pivot_base >= 0 && pivot_base < (int64_t)2147483647 - 70000, "mgpi_potrf_panel_enqueue_dev: pivot_base out of range");
+    const double* ref = nullptr;
+    MGPI_TRY(diag_ref_ok(panel, diag0, &ref));
+    return potrf_enqueue(ctx, panel, pivot_base, 1, nullptr, 1, ref);
 }
 
 extern "C" int mgpi_ctx_status_reset(mgpi_ctx* ctx) {

@@ -537,6 +537,16 @@ extern "C" int mgpi_gemm_nn_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat
     return mgpi_launch_gemm(ctx, 0, 1, 0, m, n, k, A->d, A->ld, B->d, B->ld, C->d, C->ld);
 }
 
+// C = -(A B): the accumulators start from zero and C is not read (the product with an inverse diagonal block in the variance
+// sweep of the multi-GPU driver, where C is the buffer that is broadcast next)
+extern "C" int mgpi_gemm_nn_neg_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* B, mgpi_mat* C) {
+    MGPI_REQUIRE(ctx != nullptr, "mgpi_gemm_nn_neg_dev: null ctx");
+    ctx->gemm_zero_c = 1;
+    const int rc = mgpi_gemm_nn_dev(ctx, A, B, C);
+    ctx->gemm_zero_c = 0;
+    return rc;
+}
+
 // C -= A B^T restricted to the tiles on/below the GLOBAL diagonal of a 2-D block-cyclic matrix: C is this rank's
 // local trailing matrix (local block rows bi0.., local block columns bj0.. of an nb-blocked matrix on a P x Q grid,
 // this rank at (p, q)), A (m x k) the row panel, B (n x k) the column panel.  One launch per block step.

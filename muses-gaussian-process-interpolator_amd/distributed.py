@@ -230,6 +230,8 @@ class HipTileBackend(object):
     def side_backend(self):
         if self._side is None:
             self._side = HipTileBackend(_lib.Context(device=self.ctx.device, nb=0))
+            # its panels and broadcasts run beside the main context's trailing update: on the high-priority queue
+            _lib.check(self.lib.mgpi_ctx_prefer_high_priority(self._side.ctx.handle))
         return self._side
 
     def wait(self, other):
@@ -280,10 +282,21 @@ class HipTileBackend(object):
     def status_reset(self):
         _lib.check(self.lib.mgpi_ctx_status_reset(self.ctx.handle))
 
-    def potrf_block(self, block, pivot_base):
-        """in-place Cholesky of a diagonal block, no read-back: failing pivot and sum log diag stay on the device"""
-        st = self.lib.mgpi_potrf_enqueue_dev(self.ctx.handle, block.handle, int(pivot_base))
+    def diag(self, block, out):
+        """out[i] = block[i][i]"""
+        _lib.check(self.lib.mgpi_mat_diag(self.ctx.handle, block.handle, out.handle))
+
+    def potrf_block(self, block, pivot_base, diag0=None):
+        """in-place Cholesky of a diagonal block, no read-back: failing pivot and sum log diag stay on the device.
+        diag0: the block's ORIGINAL diagonal (what its pivots are measured against)"""
+        st = self.lib.mgpi_potrf_enqueue_dev(self.ctx.handle, block.handle, int(pivot_base), diag0.handle if diag0 is not None else None)
         _lib.check(st)
+
+    def potrf_panel(self, panel, pivot_base, diag0=None):
+        """a whole local block column (rows from the diagonal block down): Cholesky of its top square block and the solve of
+        the rows below it in the same fused launches, no read-back"""
+        _lib.check(self.lib.mgpi_potrf_panel_enqueue_dev(self.ctx.handle, panel.handle, int(pivot_base),
+                                                         diag0.handle if diag0 is not None else None))
 
     def status_read(self):
         """(first failing pivot, 1-based global index, 0 = none; sum of log L_ii) since status_reset.  Synchronises."""
@@ -301,6 +314,10 @@ class HipTileBackend(object):
 
     def gemm_nn(self, c, a, b):
         _lib.check(self.lib.mgpi_gemm_nn_dev(self.ctx.handle, a.handle, b.handle, c.handle))
+
+    def gemm_nn_neg(self, c, a, b):
+        """c = -(a b); c is not read"""
+        _lib.check(self.lib.mgpi_gemm_nn_neg_dev(self.ctx.handle, a.handle, b.handle, c.handle))
 
     def trtri_neg(self, a_local, r0, c0, row_step, col_step, w, batch, out):
         """out rows [j w, (j+1) w) = -(a_local[r0 + j row_step : + w, c0 + j col_step : + w])^-1 (lower triangular blocks)"""
@@ -346,7 +363,7 @@ class HipTileBackend(object):
 class DistributedGP(object):
     """K(x,x; kernel+nugget) built, factored and solved on a P x Q grid of GPUs"""
 
-    def __init__(self, grid, backend, source_x, kernel_terms, solve_terms, nb=512):
+    def __init__(self, grid, backend, source_x, kernel_terms, solve_terms, nb=512, super_blocks=None, super_min_rows=None):
         self.g = grid
         self.be = backend
         self.nb = int(nb)
@@ -363,14 +380,31 @@ class DistributedGP(object):
         self.col_blocks = list(range(g.q, self.nblk, g.Q))
         self.mloc = len(self.row_blocks) * self.nb
         self.nloc = len(self.col_blocks) * self.nb
+        # Two-level blocking as on one GPU (csrc/chol.hip, super_width): while at least super_min_rows rows trail behind it, the
+        # trailing update is applied once per SUPER-PANEL of super_blocks block columns - contraction 1024 instead of 512, the C
+        # tiles cross HBM half as often (isolated: 57.7 -> 63.2 TFLOP/s at 16384 rows).  The first super-panel is one block wide
+        # (nothing to hide its panels behind).  MGPI_DIST_SUPER / MGPI_DIST_SUPER_MIN override.
+        self.super_blocks = int(os.environ.get('MGPI_DIST_SUPER', 2) if super_blocks is None else super_blocks)
+        self.super_min_rows = int(os.environ.get('MGPI_DIST_SUPER_MIN', 14336) if super_min_rows is None else super_min_rows)
         self.A = None
         self.logdet = None
         self.alpha = None
         self.trailing_flops = 0.0   # algorithmic flops of this rank's trailing updates on the main stream (bench.py roofline)
         self.column_flops = 0.0     # ... and of its next-panel column updates on the look-ahead stream
-        self.row_panels = None        # L[I][k] for the local block rows, every block step k (filled by factor)
-        self._row_panel_offset = None
+        self.row_panels = None        # L[I][k] for the local block rows, every block step k (filled by factor), as super-panel slabs
+        self._row_panel_view = None   # k -> (first row, first column) of L[I > k][k] inside row_panels
         self._dinv = None             # {k: -(L_kk)^-1} for the diagonal blocks this rank owns (variance sweep only)
+
+    def super_panels(self):
+        """the block columns of every super-panel, in order: [[0], [1, 2], [3, 4], .., [k], [k+1], ..]"""
+        out, k = [], 0
+        while k < self.nblk:
+            left = self.nblk - k
+            w = self.super_blocks if (k > 0 and (left - self.super_blocks) * self.nb >= self.super_min_rows) else 1
+            w = max(1, min(w, left))
+            out.append(list(range(k, k + w)))
+            k += w
+        return out
 
     # -- index helpers ------------------------------------------------------------------------------------
     def _global_index(self, blocks):
@@ -401,13 +435,21 @@ class DistributedGP(object):
                 lj = self.col_blocks.index(I)
                 t0 = max(0, self.n - I * nb)
                 be.fill_diag(be.window(self.A, li * nb + t0, nb - t0, lj * nb + t0, nb - t0), 1.0)
+        # the ORIGINAL diagonal of the diagonal blocks this rank owns: what their pivots are measured against when the block is
+        # factored, many updates later (a duplicated source row's diagonal entry is rounding noise by then)
+        owned = [k for k in range(self.nblk) if k % self.g.P == self.g.p and k % self.g.Q == self.g.q]
+        self._diag_slot = dict((k, j) for j, k in enumerate(owned))
+        self.diag0 = be.alloc(max(1, len(owned)) * nb, 1)
+        for k, j in self._diag_slot.items():
+            be.diag(be.window(self.A, (k // self.g.P) * nb, nb, (k // self.g.Q) * nb, nb), be.window(self.diag0, j * nb, nb))
 
     # -- factor -------------------------------------------------------------------------------------------
-    def _panel(self, k, be, bufs):
+    def _panel(self, k, be, bufs, wrow, wcol):
         """block step k, everything that is not the trailing update: factor the diagonal block, solve the panel
-        below it, and move the panel to every rank that needs it (row panel `wrow` for the local block rows I > k,
-        column panel `wcol` for the local block columns J > k).  Runs on whatever stream `be` enqueues to; nothing
-        is read back (the failing pivot and the log-diagonal sum accumulate on `be`'s device status)."""
+        below it, and move the panel to every rank that needs it: `wrow` receives L[I][k] for the local block rows I > k,
+        `wcol` L[J][k] for the local block columns J > k (both are nb-column windows of a super-panel's slab, or None when
+        this rank has no such rows / columns).  Runs on whatever stream `be` enqueues to; nothing is read back (the failing
+        pivot and the log-diagonal sum accumulate on `be`'s device status)."""
         g, nb, A = self.g, self.nb, self.A
         W = be.window
         pk, qk = k % g.P, k % g.Q
@@ -416,26 +458,32 @@ class DistributedGP(object):
         j0 = self._first_local(self.col_blocks, k)
         mt = self.mloc - i0 * nb                         # local trailing rows
         nt = self.nloc - j0 * nb
-        lkk = bufs['lkk']
-        # the row panel of step k lives in the persistent store (self.row_panels): the variance sweep reuses it, so
-        # L crosses xGMI once, not twice
-        wrow = W(self.row_panels, self._row_panel_offset[k], mt) if mt > 0 else None
-        wcol = W(bufs['wcol'], 0, nt) if nt > 0 else None
-        # 1. diagonal block, down its process column
         if g.q == qk:
-            if g.p == pk:
-                blk = W(A, kr * nb, nb, kc * nb, nb)
-                be.potrf_block(blk, k * nb)
-                be.copy(lkk, blk)
-            g.bcast_col(be, lkk, pk)
-            # 2. panel trsm on this process column
-            if mt > 0:
-                be.trsm_right(lkk, W(A, i0 * nb, mt, kc * nb, nb))
-        # 3. panel along process rows
+            if g.P == 1 and not g.always:
+                # one process row: the whole block column is local - the fused step kernels of the single-GPU path factor the
+                # diagonal block and solve the rows below it in the same launches (no copy of L_kk, no separate trsm)
+                be.potrf_panel(W(A, kr * nb, self.mloc - kr * nb, kc * nb, nb), k * nb, W(self.diag0, self._diag_slot[k] * nb, nb))
+            else:
+                # 1. diagonal block, down its process column
+                lkk = bufs['lkk']
+                if g.p == pk:
+                    blk = W(A, kr * nb, nb, kc * nb, nb)
+                    be.potrf_block(blk, k * nb, W(self.diag0, self._diag_slot[k] * nb, nb))
+                    be.copy(lkk, blk)
+                g.bcast_col(be, lkk, pk)
+                # 2. panel trsm on this process column
+                if mt > 0:
+                    be.trsm_right(lkk, W(A, i0 * nb, mt, kc * nb, nb))
+        # 3. panel along process rows (collectives move contiguous buffers: through `rowtmp` when there is anyone to send to)
         if mt > 0:
-            if g.q == qk:
+            if g.Q > 1 or g.always:
+                tmp = W(bufs['rowtmp'], 0, mt)
+                if g.q == qk:
+                    be.copy(tmp, W(A, i0 * nb, mt, kc * nb, nb))
+                g.bcast_row(be, tmp, qk)
+                be.copy(wrow, tmp)
+            else:
                 be.copy(wrow, W(A, i0 * nb, mt, kc * nb, nb))
-            g.bcast_row(be, wrow, qk)
         # 4. transposed role along process columns.  The blocks L[J][k] this rank needs (J = q mod Q, J > k) sit,
         #    after step 3, in the row panels of the ranks (J mod P, q) of its own process column.  For a source
         #    grid row pr the wanted J form an arithmetic progression (J = r mod lcm(P,Q)), so gathering them on
@@ -451,88 +499,133 @@ class DistributedGP(object):
                     continue
                 count = (self.nblk - 1 - J0) // lcm + 1
                 si, sj = lcm // g.P, lcm // g.Q                       # strides in local row / column blocks
+                jl0 = (J0 - g.q) // g.Q - j0
+                if g.P == 1 and not g.always:
+                    # the source is this rank: straight from the row panel into the column panel
+                    be.copy_blocks(wcol, jl0 * nb, sj * nb, wrow, ((J0 - pr) // g.P - i0) * nb, si * nb, nb, count)
+                    continue
                 buf = W(bufs['gather'], 0, count * nb)
                 if g.p == pr:
                     il0 = (J0 - pr) // g.P - i0
                     be.copy_blocks(buf, 0, nb, wrow, il0 * nb, si * nb, nb, count)
                 g.bcast_col(be, buf, pr)
-                jl0 = (J0 - g.q) // g.Q - j0
                 be.copy_blocks(wcol, jl0 * nb, sj * nb, buf, 0, nb, nb, count)
-        return dict(wrow=wrow, wcol=wcol, i0=i0, j0=j0, mt=mt, nt=nt)
+        return dict(wrow=wrow, wcol=wcol, i0=i0, j0=j0, mt=mt, nt=nt, kblocks=1)
+
+    def _panel_super(self, si, be, bufs):
+        """super-panel si: its block columns one after the other - apply the earlier panels of the super-panel to the block
+        column (contraction nb, on the process column that owns it), then the block step of `_panel` - with the row / column
+        panels landing side by side in the super-panel's slabs.  Returns what `_update` needs to apply the whole super-panel
+        (contraction len(blocks) * nb) to the local trailing matrix behind it."""
+        g, nb = self.g, self.nb
+        W = be.window
+        blocks = self.super_panels_[si]
+        k0, kl = blocks[0], blocks[-1]
+        i00 = self._first_local(self.row_blocks, k0)
+        j00 = self._first_local(self.col_blocks, k0)
+        off = self._slab_offset[si]
+        done = []
+        for h, k in enumerate(blocks):
+            i0 = self._first_local(self.row_blocks, k)
+            j0 = self._first_local(self.col_blocks, k)
+            mt, nt = self.mloc - i0 * nb, self.nloc - j0 * nb
+            if g.q == k % g.Q:                            # the block column of step k is local: bring it up to date
+                jl = k // g.Q
+                for pan in done:
+                    self._update(pan, jl, jl + 1, be)
+            wrow = W(self.row_panels, off + (i0 - i00) * nb, mt, h * nb, nb) if mt > 0 else None
+            wcol = W(bufs['wcol'], (j0 - j00) * nb, nt, h * nb, nb) if nt > 0 else None
+            done.append(self._panel(k, be, bufs, wrow, wcol))
+        # the slabs behind the LAST block of the super-panel, all of its columns
+        i0 = self._first_local(self.row_blocks, kl)
+        j0 = self._first_local(self.col_blocks, kl)
+        mt, nt = self.mloc - i0 * nb, self.nloc - j0 * nb
+        width = len(blocks) * nb
+        return dict(wrow=W(self.row_panels, off + (i0 - i00) * nb, mt, 0, width) if mt > 0 else None,
+                    wcol=W(bufs['wcol'], (j0 - j00) * nb, nt, 0, width) if nt > 0 else None,
+                    i0=i0, j0=j0, mt=mt, nt=nt, kblocks=len(blocks))
 
     def _update(self, pan, c_lo, c_hi, be):
-        """trailing update of the local block columns [c_lo, c_hi) with the panel of one block step:
-        A[I][J] -= L[I][k] L[J][k]^T for the local blocks with I >= J.  One launch (staircase gemm)."""
+        """trailing update of the local block columns [c_lo, c_hi) with the panel(s) `pan` describes:
+        A[I][J] -= sum_k L[I][k] L[J][k]^T for the local blocks with I >= J.  One launch (staircase gemm)."""
         g, nb = self.g, self.nb
         i0, j0 = pan['i0'], pan['j0']
         c_hi = min(c_hi, len(self.col_blocks))
         if pan['mt'] <= 0 or c_lo >= c_hi:
             return
         W = be.window
+        kw = pan['wrow'].cols if hasattr(pan['wrow'], 'cols') else pan['wrow'].shape[1]
         be.gemm_nt_stair(W(self.A, i0 * nb, pan['mt'], c_lo * nb, (c_hi - c_lo) * nb), pan['wrow'],
-                         W(pan['wcol'], (c_lo - j0) * nb, (c_hi - c_lo) * nb), g.P, g.p, g.Q, g.q, i0, c_lo, nb)
+                         W(pan['wcol'], (c_lo - j0) * nb, (c_hi - c_lo) * nb, 0, kw), g.P, g.p, g.Q, g.q, i0, c_lo, nb)
         flops = 0.0                                              # flop bookkeeping only (bench.py roofline)
         for jl in range(c_lo, c_hi):
             J = self.col_blocks[jl]
-            il = self._first_local(self.row_blocks, J - 1)
+            il = max(self._first_local(self.row_blocks, J - 1), i0)
             if il < len(self.row_blocks):
                 rows = self.mloc - il * nb
                 diag = nb if self.row_blocks[il] == J else 0      # a diagonal block counts as its lower half
-                flops += 2.0 * (rows - diag) * nb * nb + diag * (nb + 1.0) * nb
+                flops += (2.0 * (rows - diag) * nb + diag * (nb + 1.0)) * kw
         if be is self.be:
             self.trailing_flops += flops                         # launches timed by the main context's profile slot 0
         else:
             self.column_flops += flops                           # next-panel column updates on the look-ahead stream
 
     def factor(self, lookahead=None):
-        """2-D block-cyclic right-looking Cholesky.  With look-ahead (default; MGPI_DIST_LOOKAHEAD=0 turns it off)
-        the update of the block column of step k+1 and then step k+1's panel work - diagonal factorisation, panel
-        solve and all its broadcasts - run on a second stream while the rest of the trailing update of step k runs on
-        the main stream, so the xGMI transfers and the latency-bound panel hide behind the MFMA work.  Every rank
-        issues the same collectives in the same order in both modes, and all of them on ONE stream per mode (the
-        look-ahead stream, or the main stream without look-ahead)."""
+        """2-D block-cyclic right-looking Cholesky in super-panels.  With look-ahead (default; MGPI_DIST_LOOKAHEAD=0 turns it
+        off) the update of the block columns of super-panel s+1 and then that super-panel's work - diagonal factorisations,
+        panel solves and all their broadcasts - run on a second stream while the rest of the trailing update of super-panel s
+        runs on the main stream, so the xGMI transfers and the latency-bound panels hide behind the MFMA work.  Every rank
+        issues the same collectives in the same order in both modes, and all of them on ONE stream per mode (the look-ahead
+        stream, or the main stream without look-ahead)."""
         g, be, nb = self.g, self.be, self.nb
         self._dinv = None
         if lookahead is None:
             lookahead = os.environ.get('MGPI_DIST_LOOKAHEAD', '1') != '0'
         side = be.side_backend() if lookahead else be
-        # panel buffers: two sets (step parity), allocated once
-        bufs = [dict(lkk=be.alloc(nb, nb, zero=False), wcol=be.alloc(max(self.nloc, nb), nb, zero=False),
-                     gather=be.alloc(max(self.nloc, nb), nb, zero=False)) for _ in range(2)]
-        # persistent row panels: for every block step k the blocks L[I][k] of the local block rows I > k
-        # (sum_k (N - k nb)/P x nb doubles = 8 N^2 / (2P) bytes: 8.6 GB per rank at N = 65536 on 2 x 4)
-        offs, total = [], 0
-        for k in range(self.nblk):
+        supers = self.super_panels_ = self.super_panels()
+        wmax = max(len(b) for b in supers) * nb
+        # panel buffers: two sets (parity of the super-panel), allocated once
+        bufs = [dict(lkk=be.alloc(nb, nb, zero=False), wcol=be.alloc(max(self.nloc, nb), wmax, zero=False),
+                     gather=be.alloc(max(self.nloc, nb), nb, zero=False), rowtmp=be.alloc(max(self.mloc, nb), nb, zero=False))
+                for _ in range(2)]
+        # persistent row panels: for every super-panel a slab with the blocks L[I][k] of the local block rows I > (its first
+        # block), the panels of its block columns side by side (sum_k (N - k nb)/P x nb doubles = 8 N^2 / (2P) bytes: 8.6 GB per
+        # rank at N = 65536 on 2 x 4).  The variance sweep reuses them, so L crosses xGMI once, not twice.
+        offs, total, views = [], 0, {}
+        for blocks in supers:
             offs.append(total)
-            total += self.mloc - self._first_local(self.row_blocks, k) * nb
+            i00 = self._first_local(self.row_blocks, blocks[0])
+            for h, k in enumerate(blocks):
+                views[k] = (total + (self._first_local(self.row_blocks, k) - i00) * nb, h * nb)
+            total += self.mloc - i00 * nb
         total = max(total, nb)
-        self._row_panel_offset = offs
-        if self.row_panels is None or self.row_panels.rows != total:
-            self.row_panels = be.alloc(total, nb, zero=False)
+        self._slab_offset, self._row_panel_view = offs, views
+        if self.row_panels is None or self.row_panels.rows != total or self.row_panels.cols != wmax:
+            self.row_panels = be.alloc(total, wmax, zero=False)
         side.status_reset()
         side.wait(be)                                           # the build (and the allocations' fills) precede the first panel
 
         ncols = len(self.col_blocks)
-        pan = self._panel(0, side, bufs[0])
+        pan = self._panel_super(0, side, bufs[0])
         be.wait(side)
-        for k in range(self.nblk):
-            nxt = k + 1 < self.nblk
+        for s in range(len(supers)):
+            nxt = s + 1 < len(supers)
             j0 = pan['j0']
-            own_next = nxt and g.q == (k + 1) % g.Q              # the first local trailing column is block column k+1
             if not lookahead or not nxt:
                 self._update(pan, j0, ncols, be)
                 if nxt:
-                    pan = self._panel(k + 1, be, bufs[(k + 1) % 2])
+                    pan = self._panel_super(s + 1, be, bufs[(s + 1) % 2])
                 continue
-            # (a) main stream: the rest of the trailing update of step k.  (b) side stream (high priority): the block
-            # column of the next panel, then that panel - its diagonal factorisation, panel solve and all of its
-            # broadcasts.  The two write disjoint block columns and both only read panel k.  The side stream waits for
-            # what the main stream had queued BEFORE (a): the rest of step k-1, which wrote the columns (b) touches.
+            # (a) main stream: the rest of the trailing update of super-panel s.  (b) side stream (high priority): the block
+            # columns of the next super-panel, then that super-panel - its diagonal factorisations, panel solves and all of
+            # its broadcasts.  The two write disjoint block columns and both only read super-panel s.  The side stream waits
+            # for what the main stream had queued BEFORE (a): the rest of step s-1, which wrote the columns (b) touches.
             side.wait(be)
-            self._update(pan, j0 + 1 if own_next else j0, ncols, be)
-            if own_next:
-                self._update(pan, j0, j0 + 1, side)
-            nxt_pan = self._panel(k + 1, side, bufs[(k + 1) % 2])
+            nown = sum(1 for k in supers[s + 1] if k % g.Q == g.q)   # they are the first local trailing columns
+            self._update(pan, j0 + nown, ncols, be)
+            if nown:
+                self._update(pan, j0, j0 + nown, side)
+            nxt_pan = self._panel_super(s + 1, side, bufs[(s + 1) % 2])
             be.wait(side)
             pan = nxt_pan
         # logdet and the first failing pivot, agreed by everyone (one read-back for the whole factorisation)
@@ -554,51 +647,63 @@ class DistributedGP(object):
 
     # -- solve (replicated right-hand side) -----------------------------------------------------------------
     def solve(self, source_f):
+        """alpha = K^-1 f by two block sweeps over the distributed factor, right-looking like the single-GPU sweeps: as soon as
+        a block of the solution is known it is applied to everything it feeds - ONE wide, HBM-bound launch over the local
+        blocks L[I > k][k] (forward) resp. L[k][J < k] (backward) - into a local accumulator of partial sums.  Per block step
+        ONE small reduce of the block's partial sums (inside the process row of the diagonal block going forward, its process
+        column going backward) and ONE broadcast of the nb solved entries to the ranks that multiply with them: going
+        forward the diagonal block's process COLUMN (they hold L[I][k]), going backward its process ROW - P resp. Q members
+        instead of the whole world.  The solution is assembled once at the end (one all-reduce of N doubles, every block
+        contributed by its owner alone)."""
         g, be, nb = self.g, self.be, self.nb
         A, W = self.A, be.window
         f = np.zeros(self.np_)
         f[:self.n] = _lib.as_f64(source_f).reshape(-1)
-        y = be.alloc(self.np_, 1)                               # replicated, global order
-        be.upload(y, f)
-        ycol = be.alloc(max(self.nloc, nb), 1)                  # solved entries in local COLUMN order
-        s = be.alloc(nb, 1)
-        zero = be.alloc(nb, 1)
-        # forward: L y = f
+        y = be.alloc(self.np_, 1)                               # replicated right-hand side; block k becomes the solution on
+        be.upload(y, f)                                         # the ranks that need it
+        # forward: L y = f.  acc (local ROW order) collects  - sum_{J < I, J local} L[I][J] y_J  for every local block row I
+        acc = be.alloc(max(self.mloc, nb), 1)
         for k in range(self.nblk):
             pk, qk = k % g.P, k % g.Q
             kr, kc = k // g.P, k // g.Q
             yk = W(y, k * nb, nb)
             if g.p == pk:
-                be.copy(s, zero)
-                jc = self._first_local(self.col_blocks, k - 1)  # local col blocks [0:jc) have J < k
-                if jc > 0:
-                    be.gemv(W(A, kr * nb, nb, 0, jc * nb), W(ycol, 0, jc * nb), s, 0)     # s = -sum_J L[k][J] y_J
+                s = W(acc, kr * nb, nb)
                 g.reduce_row(be, s, qk)
                 if g.q == qk:
                     be.axpy(1.0, s, yk)
                     be.trsv(W(A, kr * nb, nb, kc * nb, nb), yk, 0)
-            g.bcast_world(be, yk, g.rank_of(pk, qk))
-            if g.q == qk:
-                be.copy(W(ycol, kc * nb, nb), yk)
-        # backward: L^T x = y
-        xrow = be.alloc(max(self.mloc, nb), 1)                  # solved entries in local ROW order
+            if g.q == qk:                                       # y_k multiplies the blocks L[I][k]: process column qk
+                g.bcast_col(be, yk, pk)
+                i0 = self._first_local(self.row_blocks, k)      # local row blocks [i0:) have I > k
+                if i0 < len(self.row_blocks):
+                    mt = self.mloc - i0 * nb
+                    be.gemv(W(A, i0 * nb, mt, kc * nb, nb), yk, W(acc, i0 * nb, mt), 0)       # acc_I -= L[I][k] y_k
+        # backward: L^T x = y  (y_k is where it was solved: on the owner of the diagonal block).  accb (local COLUMN order)
+        # collects  - sum_{I > J, I local} L[I][J]^T x_I  for every local block column J
+        accb = be.alloc(max(self.nloc, nb), 1)
         for k in range(self.nblk - 1, -1, -1):
             pk, qk = k % g.P, k % g.Q
             kr, kc = k // g.P, k // g.Q
             xk = W(y, k * nb, nb)
             if g.q == qk:
-                be.copy(s, zero)
-                i0 = self._first_local(self.row_blocks, k)      # local row blocks [i0:) have I > k
-                if i0 < len(self.row_blocks):
-                    mt = self.mloc - i0 * nb
-                    be.gemv(W(A, i0 * nb, mt, kc * nb, nb), W(xrow, i0 * nb, mt), s, 1)     # s = -sum_I L[I][k]^T x_I
+                s = W(accb, kc * nb, nb)
                 g.reduce_col(be, s, pk)
                 if g.p == pk:
                     be.axpy(1.0, s, xk)
                     be.trsv(W(A, kr * nb, nb, kc * nb, nb), xk, 1)
-            g.bcast_world(be, xk, g.rank_of(pk, qk))
-            if g.p == pk:
-                be.copy(W(xrow, kr * nb, nb), xk)
+            if g.p == pk:                                       # x_k multiplies the blocks L[k][J]^T: process row pk
+                g.bcast_row(be, xk, qk)
+                jc = self._first_local(self.col_blocks, k - 1)  # local col blocks [0:jc) have J < k
+                if jc > 0:
+                    be.gemv(W(A, kr * nb, nb, 0, jc * nb), xk, W(accb, 0, jc * nb), 1)          # accb_J -= L[k][J]^T x_k
+        if g.world > 1 or g.always:
+            out = be.alloc(self.np_, 1)                         # zero; every block from its owner, then one sum
+            for k in range(self.nblk):
+                if (g.p, g.q) == (k % g.P, k % g.Q):
+                    be.copy(W(out, k * nb, nb), W(y, k * nb, nb))
+            g.all_reduce(be, out, 'sum')
+            y = out
         self.alpha = be.download(y).reshape(-1)[:self.n].copy()
         return self.alpha
 
@@ -638,12 +743,26 @@ class DistributedGP(object):
         for j, k in enumerate(mine):
             self._dinv[k] = be.window(out, j * nb, nb)
 
-    def variance(self, target_x):
+    def variance(self, target_x, m_slab=None):
         """pointwise posterior variance: V = L^-1 K(x, x*) by the same block-cyclic sweep (queries sharded over
-        process columns, rows of V distributed like the rows of L), then column norms"""
+        process columns, rows of V distributed like the rows of L), then column norms.  The queries are processed in slabs
+        (`m_slab` per process column, default sized so that a slab's V stays near 4 GB per rank; MGPI_DIST_VAR_SLAB), as on
+        one GPU: 10^6 queries (BASELINE.json configs[4]) never need an (N/P) x (M/Q) array in one piece."""
+        g = self.g
+        xs = _lib.as_f64(target_x, ndim=2)
+        m = len(xs)
+        if m_slab is None:
+            m_slab = int(os.environ.get('MGPI_DIST_VAR_SLAB', 0)) or max(128, min(65536, (1 << 29) // max(self.mloc, 1) // 128 * 128))
+        m_slab = max(128, (int(m_slab) + 127) // 128 * 128)
+        step = m_slab * g.Q                                   # queries per sweep, all process columns together
+        out = np.empty(m)
+        for lo in range(0, m, step):
+            out[lo:lo + step] = self._variance_slab(xs[lo:lo + step])
+        return out
+
+    def _variance_slab(self, xs):
         g, be, nb = self.g, self.be, self.nb
         A, W = self.A, be.window
-        xs = _lib.as_f64(target_x, ndim=2)
         m = len(xs)
         per = (m + g.Q - 1) // g.Q
         per = (per + 127) // 128 * 128
@@ -661,8 +780,6 @@ class DistributedGP(object):
             self._ensure_dinv()
         vk = be.alloc(nb, per, zero=False)
         lkk = be.alloc(nb, nb, zero=False)
-        solved = be.alloc(nb, per)
-        zeros = be.alloc(nb, per)
         for k in range(self.nblk):
             pk, qk = k % g.P, k % g.Q
             kr, kc = k // g.P, k // g.Q
@@ -674,23 +791,27 @@ class DistributedGP(object):
             if g.p == pk:
                 Vk = W(V, kr * nb, nb)
                 if use_inv:
-                    if g.q == qk:
-                        be.copy(lkk, self._dinv[k])
-                    g.bcast_row(be, lkk, qk)
-                    be.copy(solved, zeros)
-                    be.gemm_nn(solved, lkk, Vk)                                  # 0 - (-(L_kk)^-1) V_k
-                    be.copy(Vk, solved)
+                    inv = lkk
+                    if g.Q > 1 or g.always:
+                        if g.q == qk:
+                            be.copy(lkk, self._dinv[k])
+                        g.bcast_row(be, lkk, qk)
+                    else:
+                        inv = self._dinv[k]                                      # nobody to send it to: use it where it is
+                    be.gemm_nn_neg(vk, inv, Vk)                                  # -(-(L_kk)^-1) V_k, straight into the buffer
+                    be.copy(Vk, vk)                                              # that is broadcast next
                 else:
                     if g.q == qk:
                         be.copy(lkk, W(A, kr * nb, nb, kc * nb, nb))
                     g.bcast_row(be, lkk, qk)
                     be.trsm_left(lkk, Vk)
-                be.copy(vk, Vk)
+                    be.copy(vk, Vk)
             g.bcast_col(be, vk, pk)
             # panel blocks L[I][k], I > k: every rank kept its row panel of step k from the factorisation
             # (self.row_panels), so the factor is NOT broadcast a second time
             if mt > 0:
-                be.gemm_nn(W(V, i0 * nb, mt), W(self.row_panels, self._row_panel_offset[k], mt), vk)
+                r0, c0 = self._row_panel_view[k]
+                be.gemm_nn(W(V, i0 * nb, mt), W(self.row_panels, r0, mt, c0, nb), vk)
         sq_dev = be.alloc(per, 1)
         be.colsq(V, sq_dev)
         if g.P > 1 or g.always:

@@ -76,22 +76,37 @@ class NumpyTileBackend(object):
     def status_reset(self):
         self._pivot, self._logdiag = 0, 0.0
 
-    def potrf_block(self, block, pivot_base):
-        sym = np.tril(block) + np.tril(block, -1).T
-        try:
-            L = np.linalg.cholesky(sym)
-        except np.linalg.LinAlgError:
-            cand = pivot_base + 1
-            self._pivot = cand if self._pivot == 0 else min(self._pivot, cand)
-            return
+    def diag(self, block, out):
+        out[:, 0] = np.diag(block)
+
+    def potrf_block(self, block, pivot_base, diag0=None):
+        """Cholesky with the product's pivot rule: pivot k must exceed 100 eps times the ORIGINAL diagonal entry (diag0)"""
+        ref = np.abs(np.diag(block).copy() if diag0 is None else np.asarray(diag0).reshape(-1))
+        L = np.tril(block).copy()
+        n = L.shape[0]
+        for k in range(n):
+            piv = L[k, k] - L[k, :k] @ L[k, :k]
+            if not piv > 100 * np.finfo(float).eps * ref[k]:
+                cand = pivot_base + k + 1
+                self._pivot = cand if self._pivot == 0 else min(self._pivot, cand)
+                return                          # the block is left as it was; what follows it is undefined, as on the GPU
+            L[k, k] = np.sqrt(piv)
+            L[k + 1:, k] = (L[k + 1:, k] - L[k + 1:, :k] @ L[k, :k]) / L[k, k]
         block[...] = L
         self._logdiag += float(np.sum(np.log(np.diag(L))))
+
+    def potrf_panel(self, panel, pivot_base, diag0=None):
+        w = panel.shape[1]
+        self.potrf_block(panel[:w], pivot_base, diag0)
+        if panel.shape[0] > w:
+            self.trsm_right(panel[:w], panel[w:])
 
     def status_read(self):
         return self._pivot, self._logdiag
 
     def trsm_right(self, lkk, rows):
-        rows[...] = solve_triangular(np.tril(lkk), rows.T, lower=True).T
+        with np.errstate(all='ignore'):      # after a failed pivot the factor is garbage: keep going like the GPU does
+            rows[...] = solve_triangular(np.tril(lkk), rows.T, lower=True, check_finite=False).T
 
     def gemm_nt_stair(self, c, a, b, P, p, Q, q, bi0, bj0, nb):
         for bj in range(c.shape[1] // nb):
@@ -103,6 +118,9 @@ class NumpyTileBackend(object):
 
     def gemm_nn(self, c, a, b):
         c -= a @ b
+
+    def gemm_nn_neg(self, c, a, b):
+        c[...] = -(a @ b)
 
     def trtri_neg(self, a_local, r0, c0, row_step, col_step, w, batch, out):
         out[:batch * w, :w] = 0.0

@@ -17,7 +17,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, P, Q, n, d, m, nb, port, seed, lookahead='1'):
+def _worker(rank, world, P, Q, n, d, m, nb, port, seed, lookahead='1', super_min_rows=None):
     import sys
     os.environ['MGPI_DIST_LOOKAHEAD'] = lookahead
     sys.path.insert(0, ROOT)
@@ -43,7 +43,9 @@ def _worker(rank, world, P, Q, n, d, m, nb, port, seed, lookahead='1'):
         nugget = [(1, 0.1, ())]
         grid = ProcessGrid(GlooTransport(torch, dist), P, Q)
         assert (grid.p, grid.q) == divmod(rank, Q)
-        gp = DistributedGP(grid, NumpyTileBackend(), x, kernel, kernel + nugget, nb=nb)
+        gp = DistributedGP(grid, NumpyTileBackend(), x, kernel, kernel + nugget, nb=nb, super_min_rows=super_min_rows)
+        if super_min_rows == 0:
+            assert max(len(b) for b in gp.super_panels()) == 2 and gp.super_panels()[0] == [0]
         gp.build()
         logdet = gp.factor()
         alpha = gp.solve(f)
@@ -61,6 +63,11 @@ def _worker(rank, world, P, Q, n, d, m, nb, port, seed, lookahead='1'):
         assert np.max(np.abs(alpha - ref_alpha)) < 1e-9 * np.max(np.abs(ref_alpha)), 'alpha'
         assert np.max(np.abs(mean - ref_mean)) < 1e-10 * np.max(np.abs(ref_mean)), 'mean'
         assert np.max(np.abs(var - ref_var)) < 1e-10, 'variance'
+        if super_min_rows == 0:
+            # many queries in slabs of 128 per process column: the slabbed variance sweep
+            xs_big = np.random.default_rng(seed + 1).random((300, d))
+            var_big = gp.variance(xs_big, m_slab=128)
+            assert np.max(np.abs(var_big - oracle.diag_variance_cholesky(okernel, L, xs_big, x))) < 1e-10, 'slabbed variance'
         # every rank holds the same replicated results
         t = torch.from_numpy(np.concatenate([alpha, mean, var]))
         lo, hi = t.clone(), t.clone()
@@ -98,6 +105,34 @@ def test_block_cyclic_gloo_without_lookahead(world, P, Q, n, nb):
     """the plain schedule (panel, then the whole trailing update) stays available: MGPI_DIST_LOOKAHEAD=0"""
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(world, P, Q, n, 3, 21, nb, _free_port(), 100 + n, '0'), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize('world,P,Q,n,nb,lookahead', [(1, 1, 1, 61, 8, '1'), (2, 1, 2, 70, 8, '1'), (2, 2, 1, 70, 8, '1'), (4, 2, 2, 150, 16, '1'),
+                                                       (4, 2, 2, 131, 8, '0'), (6, 2, 3, 200, 8, '1'), (8, 2, 4, 260, 8, '1')])
+def test_block_cyclic_gloo_super_panels(world, P, Q, n, nb, lookahead):
+    """two block columns per trailing update (contraction 2 nb, the schedule the GPUs run while many rows trail): with
+    super_min_rows = 0 every super-panel after the first is two blocks wide, so the within-super-panel column update, the
+    side-by-side row / column slabs and the look-ahead over two block columns are all exercised at every grid shape [r3]"""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(world, P, Q, n, 3, 21, nb, _free_port(), 300 + n, lookahead, 0), nprocs=world, join=True)
+
+
+def test_super_panel_partition():
+    """the partition rule of DistributedGP.super_panels mirrors csrc/chol.hip's super_width: first one block, then pairs while
+    enough rows trail, singles to the end"""
+    import mgpi_amd
+    from mgpi_amd.distributed import DistributedGP, LocalTransport, ProcessGrid
+
+    class NoBackend(object):
+        pass
+    gp = DistributedGP(ProcessGrid(LocalTransport(), 1, 1), NoBackend(), np.zeros((512 * 40, 3)), [], [], nb=512)
+    sp = gp.super_panels()
+    assert sp[0] == [0] and sp[1] == [1, 2] and [k for b in sp for k in b] == list(range(40))
+    widths = [len(b) for b in sp]
+    first_single = widths.index(1, 1)
+    assert all(w == 2 for w in widths[1:first_single]) and all(w == 1 for w in widths[first_single:])
+    k = sp[first_single][0]
+    assert (40 - k - 2) * 512 < 14336 <= (40 - (k - 2) - 2) * 512
 
 
 def test_choose_grid():

@@ -65,7 +65,7 @@ def test_hip_tile_backend_single_rank(n, m, nb, lookahead):
     assert err.value.pivot == n
 
 
-def _run_ranks(world, args, timeout=600):
+def _run_ranks(world, args, timeout=600, extra_env=None):
     """start `world` ranks of tests/dist_gpu_worker.py and return their outputs"""
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -73,7 +73,7 @@ def _run_ranks(world, args, timeout=600):
     s.close()
     worker = os.path.join(HERE, 'dist_gpu_worker.py')
     rdzv = os.path.join('/tmp', 'mgpi_test_rdzv_%d_%d' % (os.getpid(), port))
-    env = dict(os.environ, MGPI_RENDEZVOUS=rdzv)
+    env = dict(os.environ, MGPI_RENDEZVOUS=rdzv, **(extra_env or {}))
     procs = [subprocess.Popen([sys.executable, worker] + [str(v) for v in (r, world, port) + tuple(args)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
@@ -106,5 +106,66 @@ def test_rccl_collectives_through_the_c_abi():
 def test_hip_tile_backend_multi_rank_on_one_gpu(P, Q, n, m, nb, d, lookahead):
     """P*Q ranks share GPU 0 (gloo, host-staged collectives - tests/dist_gpu_worker.py): the multi-rank tile
     distribution with the HIP kernels, which a one-GPU box cannot otherwise run.  At most 4 ranks + this process
-    touch the card (the box allows 6)."""
+    touch the card (the box allows 6).  Once with single block columns per trailing update, once with super-panels of two
+    (MGPI_DIST_SUPER_MIN=0: contraction 2 nb, slabs side by side) - the schedule the large runs use."""
     _run_ranks(P * Q, ('staged', P, Q, n, m, nb, d, lookahead))
+    _run_ranks(P * Q, ('staged', P, Q, n, m, nb, d, lookahead), extra_env={'MGPI_DIST_SUPER_MIN': '0'})
+
+
+def test_staged_2x2_at_c2_size():
+    """the 2 x 2 grid at N = 8192 (BASELINE.json configs[1]'s size), nb = 512, look-ahead, super-panels: four ranks on GPU 0
+    with host-staged collectives, every rank against the oracle [r3: the staged tests stopped at N = 2300]"""
+    _run_ranks(4, ('staged', 2, 2, 8192, 256, 512, 3, 1), timeout=900, extra_env={'MGPI_DIST_SUPER_MIN': '2048'})
+
+
+def _single_rank_gp(x, ell, nb=512, **kw):
+    from mgpi_amd.distributed import DistributedGP, HipTileBackend, LocalTransport, ProcessGrid
+    k = mgpi.SquaredExponentialKernel(1.0, *ell)
+    nug = mgpi.WhiteNoiseKernel(1e-2)
+    ctx = mgpi.default_context()
+    gp = DistributedGP(ProcessGrid(LocalTransport(), 1, 1), HipTileBackend(ctx), x, k.terms(), (k + nug).terms(), nb=nb, **kw)
+    return gp, k, nug
+
+
+def test_single_rank_driver_at_c3_against_the_single_gpu_path():
+    """the block-cyclic driver on a 1 x 1 grid at the C3 recipe (N = 32768, D = 3, nb = 512): alpha, mean and variance against
+    the single-GPU path's to 1e-11, logdet to 1e-12 - the same matrix through two schedules (fused tall panels, super-panels of
+    two block columns, look-ahead on the side context) [r3: the driver had never run above N = 2300 under a test]"""
+    import bench
+    x, f, xs, ell, sigma, nugget_sigma = bench.make_workload('c3')
+    xq = xs[:1024]
+    gp, k, nug = _single_rank_gp(x, ell)
+    gp.build()
+    logdet = gp.factor()
+    alpha = gp.solve(f)
+    mean = gp.mean(xq)
+    var = gp.variance(xq, m_slab=512)                        # two slabs
+    del gp
+    it = mgpi.Interpolator(k, nugget=nug)
+    fit = it.fit(x, f)
+    a1 = fit.alpha.to_host().reshape(-1)
+    assert abs(logdet - fit.logdet) < 1e-12 * abs(fit.logdet)
+    assert relmax(alpha, a1) < 1e-11
+    assert relmax(mean, fit.mean(xq)) < 1e-11
+    assert np.max(np.abs(var - fit.variance(xq))) < 1e-11
+
+
+def test_single_rank_driver_at_c4_size():
+    """N = 65536, D = 4 (BASELINE.json configs[3]'s matrix) through the driver on one GPU: residual of alpha < 1e-10 via the
+    fused contraction with kernel + nugget, variance bounds, logdet against the single-GPU path"""
+    import bench
+    x, f, xs, ell, sigma, nugget_sigma = bench.make_workload('c4')
+    gp, k, nug = _single_rank_gp(x, ell)
+    gp.build()
+    logdet = gp.factor()
+    alpha = gp.solve(f)
+    q = xs[:512].copy()
+    q[:8] = x[:8]
+    var = gp.variance(q)
+    del gp
+    idx = np.linspace(0, len(x) - 1, 2048).astype(int)
+    Kalpha = mgpi.Interpolator(k + nug).predict(x[idx], x, alpha)
+    assert np.max(np.abs(Kalpha - f[idx])) / np.max(np.abs(f)) < 1e-10
+    assert np.all(var > -1e-9) and np.all(var <= 1.0 + 1e-12) and np.all(var[:8] < 1e-4 * 1.1 + 1e-9)
+    fit = mgpi.Interpolator(k, nugget=nug).fit(x)
+    assert abs(logdet - fit.logdet) < 1e-11 * abs(fit.logdet)
