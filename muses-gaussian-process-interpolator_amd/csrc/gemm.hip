@@ -389,6 +389,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_pipe_kernel(int64_t k, const 
             for (int r = 0; r < 4; ++r) c0[(i * 16 + 4 * r) * ldc + j * 16] = -acc[i][j][r];
 }
 
+// Measured and dropped (round 3): a 256 x 128 tile - 8 waves in a 4 x 2 grid, ONE workgroup per CU, otherwise this kernel
+// (same LDS image, same staging, same pipelined K loop).  25 % fewer L2 requests and 13 % less HBM-side traffic as intended,
+// but 59.7 TFLOP/s against 69.5 on the lower update at n = 32256, K = 1024 (NN, 32768 x 4096 x 2048: 64.8 against 70.5):
+// MFMA-busy 0.77 against 0.89.  With one barrier domain per CU every wave of the CU waits at the same stage boundary, where two
+// independent 4-wave workgroups fill each other's barrier, prologue and epilogue.  Counters: profiles/r03_wide_tile_pmc.md;
+// the kernel text: tools/gemm_wide_experiment.inc.
+
 static gemm_stair no_stair() {
     gemm_stair st;
     memset(&st, 0, sizeof(st));
