@@ -7,6 +7,9 @@ A *step* is one pass of the hot path over one batch of synthetic input that is a
     build K(x,x; kernel+nugget) lower tiles -> blocked Cholesky (nb=512) + alpha = K^-1 f (one call, mgpi_posv_dev)
     -> posterior mean at M queries (fused K* alpha) -> posterior variance at M queries (V = L^-1 K*^T, col norms)
 i.e. Interpolator.condition_diag() without the host<->device copies (the PCIe-inclusive rate is in DESIGN.md).
+Round 3: like condition_diag() itself, the step lets K* ride below K through the factorisation where that pays (N <= 16384 and
+M <= N, e.g. --workload c2: one pass builds, factors, solves and forward-solves V^T = K* L^-T; mgpi_posv_riders_dev) - the same
+arithmetic work, counted the same way.  The default workload (C3) keeps the two-pass form.
 
 Workload at N=1 (config.workload): BASELINE.json configs[2] = C3, N=32768 D=3 jittered grid, SE + WhiteNoise
 nugget, nb=512, M=4096 queries - the configuration north_star quotes its target on ("the Cholesky trailing
@@ -201,7 +204,19 @@ class GpuStep(object):
         self.X = DM.from_host(self.ctx, x)
         self.XS = DM.from_host(self.ctx, xs)
         self.F = DM.from_host(self.ctx, f)
-        self.L = DM(self.ctx, self.n, self.n, wide=True)
+        # condition_diag's form (gp.py, riders_pay): in the chain-bound regime (N <= 16384, no more queries than sources) K(x*, x)
+        # rides below K through the factorisation (mgpi_cov_riders_dev / mgpi_posv_riders_dev) and the variance is read off the
+        # rider rows; C3 / C4 and the million queries of C5 go through the finished factor (mgpi_predict_var_dev).
+        from mgpi_amd.gp import riders_pay
+        self.ride = riders_pay(self.n, self.m)              # the rule Interpolator.condition_diag applies
+        if self.ride:
+            pn = (self.n + 127) // 128 * 128
+            self.KR = DM(self.ctx, pn + self.m, self.n, wide=True)
+            hv = _lib._vp()
+            _lib.check(self.lib.mgpi_mat_square_view(self.KR.handle, self.ct.byref(hv)))
+            self.L = DM(self.ctx, self.n, self.n, handle=hv, parent=self.KR)
+        else:
+            self.L = DM(self.ctx, self.n, self.n, wide=True)
         self.alpha = DM(self.ctx, self.n, 1)
         self.mean = DM(self.ctx, self.m, 1)
         self.var = DM(self.ctx, self.m, 1)
@@ -209,6 +224,15 @@ class GpuStep(object):
 
     def run(self):
         c, h, lib = self.lib_mod.check, self.ctx.handle, self.lib
+        if self.ride:
+            c(lib.mgpi_cov_riders_dev(h, self.X.handle, self.XS.handle, self.kdesc[0], self.kdesc[1], self.sdesc[0], self.sdesc[1],
+                                      self.KR.handle))
+            c(lib.mgpi_mat_copy(h, self.F.handle, self.alpha.handle))
+            c(lib.mgpi_posv_riders_dev(h, self.KR.handle, self.alpha.handle, None))   # factor + solve + V^T = K* L^-T in one pass
+            c(lib.mgpi_predict_mean_dev(h, self.XS.handle, self.X.handle, self.kdesc[0], self.kdesc[1],
+                                        self.alpha.handle, self.mean.handle))
+            c(lib.mgpi_riders_var_dev(h, self.KR.handle, self.XS.handle, self.kdesc[0], self.kdesc[1], self.var.handle))
+            return
         c(lib.mgpi_cov_matrix_dev(h, self.X.handle, None, self.sdesc[0], self.sdesc[1], 1, self.L.handle))
         c(lib.mgpi_mat_copy(h, self.F.handle, self.alpha.handle))
         c(lib.mgpi_posv_dev(h, self.L.handle, self.alpha.handle, None))      # factor + solve: what Interpolator.fit() calls
@@ -239,6 +263,22 @@ class GpuStep(object):
             ctx.tic()
             fn()
             out[name] = ctx.toc()
+        if self.ride:
+            stage('build_K_lower_and_Kstar', lambda: c(lib.mgpi_cov_riders_dev(h, self.X.handle, self.XS.handle, self.kdesc[0], self.kdesc[1],
+                                                                                 self.sdesc[0], self.sdesc[1], self.KR.handle)))
+            c(lib.mgpi_mat_copy(h, self.F.handle, self.alpha.handle))
+            ctx.set_profile(True)
+            # one call: factorisation + forward sweep of alpha beside it + the riders' forward solve inside it + backward sweep
+            stage('posv_with_riders', lambda: c(lib.mgpi_posv_riders_dev(h, self.KR.handle, self.alpha.handle, None)))
+            out['potrs'] = ctx.get_profile(6)[0]            # the backward sweep: what the solve still costs
+            out['riders_update_launches'] = ctx.get_profile(4)[0]
+            ctx.set_profile(False)
+            out['potrf_and_variance_solve'] = out['posv_with_riders'] - out['potrs']
+            stage('predict_mean', lambda: c(lib.mgpi_predict_mean_dev(h, self.XS.handle, self.X.handle, self.kdesc[0], self.kdesc[1],
+                                                                      self.alpha.handle, self.mean.handle)))
+            stage('variance_from_riders', lambda: c(lib.mgpi_riders_var_dev(h, self.KR.handle, self.XS.handle, self.kdesc[0], self.kdesc[1],
+                                                                            self.var.handle)))
+            return out
         stage('build_K_lower', lambda: c(lib.mgpi_cov_matrix_dev(h, self.X.handle, None, self.sdesc[0], self.sdesc[1], 1, self.L.handle)))
         # factor + solve is ONE call (mgpi_posv_dev): the forward sweep of the solve runs beside the factorisation, the backward
         # sweep after it.  'potrs' = that backward sweep (HIP-event pair inside the library, profile slot 6): what the solve
@@ -559,8 +599,12 @@ def main():
         if stages is not None:
             out['stages_ms_one_pass'] = stages
             # stage-level rates of that one pass: every launch of the stage, both streams, against its algorithmic flops
-            out['stage_tflops_one_pass'] = {'potrf': n**3 / 3.0 / (stages['potrf'] * 1e-3) / 1e12,
-                                            'predict_var': float(n) * n * m / (stages['predict_var'] * 1e-3) / 1e12}
+            if 'potrf' in stages:
+                out['stage_tflops_one_pass'] = {'potrf': n**3 / 3.0 / (stages['potrf'] * 1e-3) / 1e12,
+                                                'predict_var': float(n) * n * m / (stages['predict_var'] * 1e-3) / 1e12}
+            else:       # riders: the variance solve's N^2 M flops run inside the factorisation's launches
+                out['stage_tflops_one_pass'] = {'potrf_and_variance_solve': (n**3 / 3.0 + float(n) * n * m) /
+                                                (stages['potrf_and_variance_solve'] * 1e-3) / 1e12}
             out['predict_mean'] = {'pairs_per_s': timed_pairs / (timed[5][0] * 1e-3) if timed[5][0] > 0 else None,
                                    'ms_per_step': timed[5][0] / args.steps}
         out['check'] = check

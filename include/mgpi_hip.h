@@ -143,6 +143,19 @@ int  mgpi_potrs_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* B);
  * forward sweep runs beside the factorisation, so the solve costs the backward sweep only; the arithmetic
  * is that of mgpi_potrf_dev followed by mgpi_potrs_dev.  Same return convention as mgpi_potrf_dev. */
 int  mgpi_posv_dev(mgpi_ctx* ctx, mgpi_mat* K, mgpi_mat* B, double* logdet);
+/* factor, solve and forward-solve "riders" in one call - Interpolator.condition's three steps (mgpi/interpolators.py:148-199)
+ * fused: KR is a wide matrix of n columns and pn + m rows (pn = n rounded up to 128); mgpi_cov_riders_dev writes
+ * K(x, x; kernel + nugget) (lower tiles) into rows [0, n) and the riders K(x*, x; kernel) into rows [pn, pn + m);
+ * mgpi_posv_riders_dev leaves L in the top square, V^T = K* L^-T in the rider rows (solved by the panels' own substitutions,
+ * updated inside the trailing-update launches) and K^-1 B in B (an (n x 1) vector, may be NULL); mgpi_riders_var_dev turns the
+ * rider rows into the posterior variance var_i = k(x*_i, x*_i) - |V^T_i|^2.  mgpi_mat_square_view hands out the factor as a
+ * square handle for the entry points that take L. */
+int  mgpi_cov_riders_dev(mgpi_ctx* ctx, const mgpi_mat* X, const mgpi_mat* Xs, const mgpi_kernel_desc* kterms, int nk,
+                         const mgpi_kernel_desc* sterms, int ns, mgpi_mat* KR);
+int  mgpi_posv_riders_dev(mgpi_ctx* ctx, mgpi_mat* KR, mgpi_mat* B, double* logdet);
+int  mgpi_riders_var_dev(mgpi_ctx* ctx, const mgpi_mat* KR, const mgpi_mat* Xs, const mgpi_kernel_desc* terms, int nterms,
+                         mgpi_mat* var);
+int  mgpi_mat_square_view(const mgpi_mat* m, mgpi_mat** out);
 /* host convenience: b (n, nrhs) row-major host in, x out (may alias) */
 int  mgpi_potrs(mgpi_ctx* ctx, const mgpi_mat* L, const double* b, int64_t n, int nrhs, double* x);
 /* Interpolator.loglikelihood (interpolators.py:331-343) for `batch` kernel parameter sets at once, x and f resident:

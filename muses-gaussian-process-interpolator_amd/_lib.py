@@ -84,6 +84,10 @@ _SIGNATURES = {
     'mgpi_potrf_dev': (ctypes.c_int, [_vp, _vp, c_double_p]),
     'mgpi_potrs_dev': (ctypes.c_int, [_vp, _vp, _vp]),
     'mgpi_posv_dev': (ctypes.c_int, [_vp, _vp, _vp, c_double_p]),
+    'mgpi_cov_riders_dev': (ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(KernelDesc), ctypes.c_int, ctypes.POINTER(KernelDesc), ctypes.c_int, _vp]),
+    'mgpi_posv_riders_dev': (ctypes.c_int, [_vp, _vp, _vp, c_double_p]),
+    'mgpi_riders_var_dev': (ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(KernelDesc), ctypes.c_int, _vp]),
+    'mgpi_mat_square_view': (ctypes.c_int, [_vp, ctypes.POINTER(_vp)]),
     'mgpi_potrs': (ctypes.c_int, [_vp, _vp, _vp, c_int64, ctypes.c_int, _vp]),
     'mgpi_trsm_dev': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
     'mgpi_loglikelihood_batch': (ctypes.c_int, [_vp, _vp, _vp, ctypes.POINTER(KernelDesc), ctypes.c_int, ctypes.c_int, _vp, _vp]),

@@ -47,6 +47,10 @@ struct trsv_diag_src {
 static void launch_trsv_diag(hipStream_t stream, const double* L, int64_t lda, double* v, int w, int trans, const trsv_diag_src* diag = nullptr);
 static void launch_trsv_update(hipStream_t stream, const double* L, int64_t lda, double* v, int64_t r0, int w, int64_t first,
                                int64_t count, int trans, const double* warm = nullptr, int warm_w = 0);
+// A (m rows x w columns, row stride lda) <- A L^-T for the factored w x w diagonal block L (row stride ldl); strip: where the
+// 64 x 64 diagonal tiles of L are read from during a factorisation (row r of the block at strip + 64 r), or nullptr (in L)
+static int launch_trsm_right_steps(hipStream_t stream, double* A, int64_t lda, int64_t m, const double* L, int64_t ldl, int64_t w,
+                                   const double* strip);
 
 // ---- ONE launch per 64-column step of a panel (round 2) -----------------------------------------------------------------
 // Step j of a panel (diagonal block at row / column c0) used to be three launches on the chain the trailing update waits
@@ -437,10 +441,26 @@ static int streams_overlap(mgpi_ctx* ctx) {
 //               pivot is measured against.  A block that earlier block steps have already updated no longer shows them - the
 //               diagonal entry of a duplicated source row is rounding noise by then, and noise above 100 eps times noise would
 //               pass - so the multi-GPU driver hands them in (it keeps the diagonal of K from the build).
+//   rider_rows  0, or pm (a multiple of 128): the matrix has pm more rows below its pn x pn square, R (pm x pn) - "riders".  They
+//               take part in every panel solve and every column update like the rows of K below the panel (the rows simply run
+//               on), and after every trailing update of the square ONE more NT gemm on the main stream applies the super-panel to
+//               the rider columns behind the next one - so that they end as R L^-T: the forward solve of a multi-right-hand-side
+//               system (V^T = K* L^-T of the posterior variance) INSIDE the factorisation instead of a blocked triangular solve of
+//               its own afterwards.  The same N^2 M flops, solved by the panels' own substitutions, no second chain of
+//               diagonal-block solves.  bench.py steps, same box (two-pass form / this): C2 13.94 / 12.99 ms, C3 260.0 / 258.6.
+//               Measured and dropped (profiles/r03_riders_ab.md): the riders' update on the third stream beside the square's
+//               (C2 14.35, C3 262.6); inside the square's launch as a trapezoid tile list (14.03 / 263.8: the next panel's
+//               block column then waits for the rider tiles too); the riders as a sweep of their own one super-panel behind
+//               (solve on the third stream from the strip's diagonal tiles: 8 substitution launches per panel, a second latency
+//               chain the main stream ends up waiting for: 13.37 / 261.0).
 static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int keep_status, double* fwd_rhs = nullptr, int tall = 0,
-                         const double* diag_ref = nullptr) {
+                         const double* diag_ref = nullptr, int64_t rider_rows = 0) {
     MGPI_REQUIRE(ctx && K, "mgpi_potrf_dev: null pointer");
-    if (!tall) {
+    if (!tall && rider_rows > 0) {
+        MGPI_REQUIRE(rider_rows % MGPI_TILE == 0 && K->pcols % MGPI_TILE == 0 && K->prows >= K->pcols + rider_rows && K->cols <= K->pcols,
+                     "mgpi_posv_riders_dev: matrix is %lld x %lld (padded %lld x %lld), riders %lld", (long long)K->rows,
+                     (long long)K->cols, (long long)K->prows, (long long)K->pcols, (long long)rider_rows);
+    } else if (!tall) {
         MGPI_REQUIRE(K->rows == K->cols, "mgpi_potrf_dev: matrix is %lld x %lld, not square", (long long)K->rows, (long long)K->cols);
         MGPI_REQUIRE(K->pcols >= K->prows || K->pcols >= mgpi_roundup(K->rows, IB),
                      "mgpi_potrf_dev: matrix must be tile padded (allocate with cols > %d)", MGPI_MAX_D);
@@ -454,8 +474,9 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
         mgpi_pool_free(ctx, K->dinv, K->dinv_bytes);
         K->dinv = nullptr;
     }
-    const int64_t n = K->rows;
-    const int64_t pn = tall ? K->prows : (K->prows <= K->pcols ? K->prows : mgpi_roundup(n, IB));   // rows of the factored extent (multiple of 64)
+    const int64_t n = rider_rows > 0 ? K->cols : K->rows;
+    const int64_t pn = tall ? K->prows : (rider_rows > 0 ? K->pcols : (K->prows <= K->pcols ? K->prows : mgpi_roundup(n, IB)));   // rows of the factored extent (multiple of 64)
+    const int64_t pm = rider_rows, prow = pn + pm;                                // riders: rows [pn, prow)
     const int64_t ncols = tall ? K->pcols : pn;                                   // columns that get factored
     const int64_t ndiag = tall ? K->pcols : n;                                    // diagonal entries that enter sum log L_ii
     const int64_t lda = K->ld;
@@ -494,9 +515,9 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     static const int64_t step_rows = getenv("MGPI_PANEL_STEP_ROWS") ? atoll(getenv("MGPI_PANEL_STEP_ROWS")) : 8192;
     int64_t strip_first = pn / IB;                      // first 64-block whose factored diagonal block waits in the scratch strip
     auto factor_panel = [&](int64_t r0, int64_t w) -> int {
-        const bool split = pn - r0 - IB > step_rows;
+        const bool split = prow - r0 - IB > step_rows;
         for (int64_t c0 = r0; c0 < r0 + w; c0 += IB) {
-            MGPI_TRY(launch_panel_step(ctx, A, lda, c0, c0 > r0 ? 1 : 0, pn - c0 - IB, r0 + w, pivot_base + c0, ctx->d_diag + c0,
+            MGPI_TRY(launch_panel_step(ctx, A, lda, c0, c0 > r0 ? 1 : 0, prow - c0 - IB, r0 + w, pivot_base + c0, ctx->d_diag + c0,
                                        ctx->d_diag + ctx->diag_len + c0 * IB, split));
             if (c0 / IB < strip_first) strip_first = c0 / IB;
         }
@@ -529,14 +550,14 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     static const int64_t inner_w = getenv("MGPI_PANEL_INNER") ? atoll(getenv("MGPI_PANEL_INNER")) : 256;
     static const int64_t inner_rows = getenv("MGPI_PANEL_INNER_ROWS") ? atoll(getenv("MGPI_PANEL_INNER_ROWS")) : 8192;
     auto factor_super = [&](int64_t c0, int64_t wc, bool on_side) -> int {
-        const int64_t nb = (inner_w >= IB && inner_w % IB == 0 && inner_w < ctx->nb && pn - c0 - wc > inner_rows) ? inner_w : ctx->nb;
+        const int64_t nb = (inner_w >= IB && inner_w % IB == 0 && inner_w < ctx->nb && prow - c0 - wc > inner_rows) ? inner_w : ctx->nb;
         for (int64_t p0 = c0; p0 < c0 + wc; p0 += nb) {
             const int64_t w = (c0 + wc - p0 < nb) ? (c0 + wc - p0) : nb;
             ctx->lean = on_side ? 1 : 0;
             int rc = factor_panel(p0, w);
             ctx->lean = 0;
             if (rc) return rc;
-            const int64_t p1 = p0 + w, rem = c0 + wc - p1, t = pn - p1;
+            const int64_t p1 = p0 + w, rem = c0 + wc - p1, t = prow - p1;
             if (rem > 0 && t > 0)    // the rest of the super-panel's columns: A[p1:pn, p1:c0+wc] -= P P[0:rem]^T
                 MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, t, rem, w, A + p1 * lda + p0, lda, A + p1 * lda + p0, lda,
                                           A + p1 * lda + p1, lda));
@@ -574,6 +595,16 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
         }
         MGPI_HIP_TRY(hipGetLastError());
         return 0;
+    };
+    // riders (rows [pn, prow)), super-panel k in columns [r0, r0 + w): R[:, c_lo:c_hi] -= R[:, r0:r0+w] A[c_lo:c_hi, r0:r0+w]^T, a
+    // plain NT gemm on the shipped kernel, on whatever ctx->stream is
+    auto rider_update = [&](int64_t r0, int64_t w, int64_t c_lo, int64_t c_hi) -> int {
+        if (pm <= 0 || c_hi <= c_lo) return 0;
+        mgpi_prof_begin(ctx, 4);
+        const int rc = mgpi_launch_gemm(ctx, 0, 0, 0, pm, c_hi - c_lo, w, A + pn * lda + r0, lda, A + c_lo * lda + r0, lda, A + pn * lda + c_lo, lda);
+        mgpi_prof_end(ctx, 4);
+        mgpi_prof_flops(ctx, 4, 2.0 * (double)pm * (double)(c_hi - c_lo) * (double)w);
+        return rc;
     };
     // Merged trailing update (round 2, second half).  The block column of super-panel k+1 used to be updated by a gemm of its
     // own on the second stream, beside the main stream's update of the rest: a skinny launch (24.7 ms of stream time per
@@ -628,6 +659,7 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
             MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 1, t, t, w, Pt, lda, Pt, lda, A + r1 * lda + r1, lda));
             mgpi_prof_end(ctx, 0);
             mgpi_prof_flops(ctx, 0, (double)t * ((double)t + 1.0) * (double)w);
+            MGPI_TRY(rider_update(r0, w, r1, pn));
             mgpi_prof_begin(ctx, 1);
             MGPI_TRY(factor_panel(r1, t));
             mgpi_prof_end(ctx, 1);
@@ -647,6 +679,7 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
             MGPI_TRY(mgpi_launch_syrk_merged(ctx, t, w, P, lda, A + r1 * lda + r1, lda, cw, d_sync));
             mgpi_prof_end(ctx, 0);
             mgpi_prof_flops(ctx, 0, (double)t * ((double)t + 1.0) * (double)w);
+            MGPI_TRY(rider_update(r0, w, r1 + w1, pn));      // riders, columns behind the next super-panel (main stream)
             // the first wait of a factorisation also orders the second stream behind the reset of the counter
             if (!merged_prev) MGPI_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_upd, 0));
             MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
@@ -654,7 +687,10 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
             hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(64), 0, ctx->stream2, d_sync, sync_target, ctx->d_info);
             MGPI_HIP_TRY(hipGetLastError());
             ctx->stream = ctx->stream2;
-            int rc = factor_super(r1, w1, true);
+            // riders, the next super-panel's columns: behind the count - the launch that bumps it started after the previous
+            // step's rider update on the main stream, which wrote these columns last
+            int rc = rider_update(r0, w, r1, r1 + w1);
+            if (rc == 0) rc = factor_super(r1, w1, true);
             if (rc == 0) rc = forward_columns(r1, r1 + w1);
             ctx->stream = main_stream;
             MGPI_TRY(rc);
@@ -670,7 +706,7 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
             MGPI_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_upd, 0));
             ctx->stream = ctx->stream2;
             mgpi_prof_begin(ctx, 3);
-            int rc = mgpi_launch_gemm(ctx, 0, 0, 0, t, w1, w, P, lda, P, lda, A + r1 * lda + r1, lda);
+            int rc = mgpi_launch_gemm(ctx, 0, 0, 0, t + pm, w1, w, P, lda, P, lda, A + r1 * lda + r1, lda);    // rider rows follow the square's
             mgpi_prof_end(ctx, 3);
             if (rc == 0) rc = factor_super(r1, w1, true);
             if (rc == 0) rc = forward_columns(r1, r1 + w1);
@@ -685,11 +721,12 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
                 MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 1, t2, t2, w, P2, lda, P2, lda, A + (r1 + w1) * lda + (r1 + w1), lda));
                 mgpi_prof_end(ctx, 0);
                 mgpi_prof_flops(ctx, 0, (double)t2 * ((double)t2 + 1.0) * (double)w);
+                MGPI_TRY(rider_update(r0, w, r1 + w1, pn));
             }
             MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
         } else {
             mgpi_prof_begin(ctx, 3);
-            MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, t, w1, w, P, lda, P, lda, A + r1 * lda + r1, lda));
+            MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 0, t + pm, w1, w, P, lda, P, lda, A + r1 * lda + r1, lda));
             mgpi_prof_end(ctx, 3);
             mgpi_prof_begin(ctx, 1);
             MGPI_TRY(factor_super(r1, w1, false));
@@ -701,6 +738,7 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
                 MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 1, t2, t2, w, P2, lda, P2, lda, A + (r1 + w1) * lda + (r1 + w1), lda));
                 mgpi_prof_end(ctx, 0);
                 mgpi_prof_flops(ctx, 0, (double)t2 * ((double)t2 + 1.0) * (double)w);
+                MGPI_TRY(rider_update(r0, w, r1 + w1, pn));
             }
         }
         r0 = r1;
@@ -779,6 +817,37 @@ extern "C" int mgpi_posv_dev(mgpi_ctx* ctx, mgpi_mat* K, mgpi_mat* B, double* lo
     MGPI_TRY(potrf_status(ctx, K, logdet));
     mgpi_prof_begin(ctx, 6);
     const int rc = trsv_sweeps(ctx, K, B->d, 2);
+    mgpi_prof_end(ctx, 6);
+    return rc;
+}
+
+// Factor, solve AND forward-solve the riders in one call.  KR is a wide matrix of n columns (padded pn) and pn + m rows: rows
+// [0, n) hold K (lower tiles), rows [pn, pn + m) the riders R = K(x*, x) (mgpi_cov_riders_dev builds both).  On return the top
+// square is L, the rider rows hold R L^-T = V^T with V = L^-1 K(x, x*) - the matrix whose column norms the posterior variance
+// subtracts (mgpi/interpolators.py:199: cov = K** - K* K^-1 K*^T, diagonal only) - and B (may be NULL) holds K^-1 B.  The riders
+// are solved by the panels' own substitutions and updated inside the trailing-update launches (potrf_enqueue, rider_rows).
+extern "C" int mgpi_posv_riders_dev(mgpi_ctx* ctx, mgpi_mat* KR, mgpi_mat* B, double* logdet) {
+    MGPI_REQUIRE(ctx && KR, "mgpi_posv_riders_dev: null pointer");
+    const int64_t pn = KR->pcols, pm = KR->prows - KR->pcols;
+    MGPI_REQUIRE(pm >= MGPI_TILE && pm % MGPI_TILE == 0 && pn % MGPI_TILE == 0,
+                 "mgpi_posv_riders_dev: need a (pn + pm) x pn matrix with pm >= %d rider rows (padded %lld x %lld)", MGPI_TILE,
+                 (long long)KR->prows, (long long)KR->pcols);
+    double* rhs = nullptr;
+    if (B != nullptr) {
+        MGPI_REQUIRE(B->rows == KR->cols && B->cols == 1 && B->ld == 1 && B->prows >= pn, "mgpi_posv_riders_dev: B must be an (n x 1) vector");
+        rhs = B->d;
+    }
+    MGPI_TRY(potrf_enqueue(ctx, KR, 0, 0, rhs, 0, nullptr, pm));
+    MGPI_TRY(potrf_status(ctx, KR, logdet));
+    if (rhs == nullptr) return 0;
+    // the backward sweep runs on the top square only: a non-owning square handle over it
+    mgpi_mat L = *KR;
+    L.rows = L.cols = KR->cols;
+    L.prows = L.pcols = pn;
+    L.owns = 0;
+    L.dinv = nullptr;
+    mgpi_prof_begin(ctx, 6);
+    const int rc = trsv_sweeps(ctx, &L, rhs, 2);
     mgpi_prof_end(ctx, 6);
     return rc;
 }
@@ -1615,7 +1684,7 @@ extern "C" int mgpi_potrs(mgpi_ctx* ctx, const mgpi_mat* L, const double* b, int
 // workgroups apply the previous columns to the remaining column blocks.  One launch per step instead of two.
 __global__ __launch_bounds__(256, 2) void trsm_right_step_kernel(double* __restrict__ A, int64_t lda, int nrowblk,
                                                                  const double* __restrict__ Lk, int64_t ldl, int64_t c0, int has_prev,
-                                                                 int rest_cols) {
+                                                                 int rest_cols, const double* __restrict__ strip) {
     __shared__ panel_lds s;
     MGPI_CHAIN_PRIO();
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
@@ -1636,14 +1705,33 @@ __global__ __launch_bounds__(256, 2) void trsm_right_step_kernel(double* __restr
     panel_load(acc, A + r0 * lda + c0, lda, w, g, c, false);
     if (has_prev) panel_gemm_nt(acc, A + (r0 + 16 * w + c) * lda + cp + 2 * g, Lk + (c0 + c) * ldl + cp + 2 * g, ldl, 0, 4);
     // images of the factored 64 x 64 diagonal sub-block: Lt[k][m] = L[m][k] (m >= k), 0 above; 1 / diagonal
+    // (during a factorisation the 64 x 64 diagonal tiles still wait in the scratch strip, row r of the block at strip + 64 r)
+    const double* Dt = strip ? strip + c0 * IB : Lk + c0 * ldl + c0;
+    const int64_t dts = strip ? IB : ldl;
     for (int i = tid; i < IB * IB; i += 256) {
         const int m = i >> 6, k = i & 63;                          // coalesced read of L[m][k]
-        s.Lt[k][m] = (m >= k) ? Lk[(c0 + m) * ldl + c0 + k] : 0.0;
+        s.Lt[k][m] = (m >= k) ? Dt[m * dts + k] : 0.0;
     }
-    if (tid < IB) s.invd[tid] = 1.0 / Lk[(c0 + tid) * ldl + c0 + tid];
+    if (tid < IB) s.invd[tid] = 1.0 / Dt[tid * dts + tid];
     __syncthreads();
     panel_trsm_images(s, tid);
     trsm_acc_mx<0>::run(acc, s, w, g, c, A + (r0 + 16 * w + c) * lda + c0);
+}
+
+static int launch_trsm_right_steps(hipStream_t stream, double* A, int64_t lda, int64_t m, const double* L, int64_t ldl, int64_t w,
+                                   const double* strip) {
+    MGPI_REQUIRE(w % IB == 0 && m % IB == 0 && m / IB < 32768, "trsm_right: %lld rows x %lld columns (multiples of %d, at most 2 M rows)",
+                 (long long)m, (long long)w, IB);
+    const int nrowblk = (int)(m / IB);
+    if (nrowblk == 0) return 0;
+    for (int64_t c0 = 0; c0 < w; c0 += IB) {
+        const int has_prev = c0 > 0;
+        const int rest_cols = has_prev ? (int)((w - c0 - IB) / IB) : 0;
+        hipLaunchKernelGGL(trsm_right_step_kernel, dim3((unsigned)(nrowblk * (1 + rest_cols))), dim3(256), 0, stream, A, lda, nrowblk, L, ldl,
+                           c0, has_prev, rest_cols, strip);
+    }
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 extern "C" int mgpi_trsm_right_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* A) {
@@ -1652,17 +1740,7 @@ extern "C" int mgpi_trsm_right_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* A
                  (long long)A->cols, (long long)L->rows, (long long)L->cols);
     MGPI_REQUIRE(L->rows % IB == 0 && A->prows % IB == 0, "mgpi_trsm_right_dev: dimensions must be multiples of %d", IB);
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
-    const int64_t w = L->rows, m = A->prows;
-    MGPI_REQUIRE(m / IB < 32768, "mgpi_trsm_right_dev: %lld rows are more than one launch covers", (long long)m);
-    const int nrowblk = (int)(m / IB);
-    for (int64_t c0 = 0; c0 < w; c0 += IB) {
-        const int has_prev = c0 > 0;
-        const int rest_cols = has_prev ? (int)((w - c0 - IB) / IB) : 0;
-        hipLaunchKernelGGL(trsm_right_step_kernel, dim3((unsigned)(nrowblk * (1 + rest_cols))), dim3(256), 0, ctx->stream, A->d, A->ld,
-                           nrowblk, L->d, L->ld, c0, has_prev, rest_cols);
-    }
-    MGPI_HIP_TRY(hipGetLastError());
-    return 0;
+    return launch_trsm_right_steps(ctx->stream, A->d, A->ld, A->prows, L->d, L->ld, L->rows, nullptr);
 }
 
 // one triangular half-solve with a factored diagonal block on an (n x 1) vector: L y = b (trans = 0), L^T x = b (1)

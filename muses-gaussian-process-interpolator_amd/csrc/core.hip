@@ -412,6 +412,26 @@ extern "C" int mgpi_mat_view(const mgpi_mat* m, int64_t r0, int64_t c0, int64_t 
     return 0;
 }
 
+// the factor inside a riders matrix (mgpi_posv_riders_dev) as a square handle of its own: rows = cols = n, padded pn x pn,
+// non-owning - what the entry points that take "the Cholesky factor L" expect (mgpi_potrs_dev, mgpi_predict_var_dev, ..)
+extern "C" int mgpi_mat_square_view(const mgpi_mat* m, mgpi_mat** out) {
+    MGPI_REQUIRE(m != nullptr && out != nullptr, "mgpi_mat_square_view: null pointer");
+    MGPI_REQUIRE(m->prows >= m->pcols && m->cols <= m->pcols, "mgpi_mat_square_view: %lld x %lld (padded %lld x %lld) has no leading square",
+                 (long long)m->rows, (long long)m->cols, (long long)m->prows, (long long)m->pcols);
+    mgpi_mat* v = new (std::nothrow) mgpi_mat();
+    if (!v) { mgpi_set_error("mgpi_mat_square_view: out of host memory"); return MGPI_ERR_ALLOC; }
+    *v = *m;
+    v->rows = v->cols = m->cols;
+    v->prows = v->pcols = m->pcols;
+    v->owns = 0;
+    v->alloc_bytes = 0;
+    v->dinv = nullptr;
+    v->dinv_nb = 0;
+    v->dinv_bytes = 0;
+    *out = v;
+    return 0;
+}
+
 // non-owning handle over caller-provided device memory (e.g. a buffer another library allocated): exactly
 // rows x cols, row stride ld; the caller guarantees the dimensions it later passes to tile kernels are padded
 extern "C" int mgpi_mat_wrap(mgpi_ctx* ctx, void* devptr, int64_t rows, int64_t cols, int64_t ld, int factored, mgpi_mat** out) {

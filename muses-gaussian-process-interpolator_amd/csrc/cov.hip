@@ -324,6 +324,26 @@ extern "C" int mgpi_cov_matrix_dev(mgpi_ctx* ctx, const mgpi_mat* X1, const mgpi
                            lower_only, /*pad_identity=*/sym, out->d, out->ld);
 }
 
+// K(x, x; sterms) lower tiles into rows [0, n) of KR and K(x*, x; kterms) into rows [pn, pn + m): the matrix mgpi_posv_riders_dev
+// factors (the three _x2cov calls of Interpolator.condition, mgpi/interpolators.py:148-169, minus K** whose diagonal is taken later)
+extern "C" int mgpi_cov_riders_dev(mgpi_ctx* ctx, const mgpi_mat* X, const mgpi_mat* Xs, const mgpi_kernel_desc* kterms, int nk,
+                                   const mgpi_kernel_desc* sterms, int ns, mgpi_mat* KR) {
+    MGPI_REQUIRE(ctx && X && Xs && KR && kterms && sterms, "mgpi_cov_riders_dev: null pointer");
+    MGPI_REQUIRE(Xs->cols == X->cols, "conflicting number of dimensions for x1 and x2 (%lld vs %lld)", (long long)Xs->cols,
+                 (long long)X->cols);   // interpolators.py:219
+    const int64_t n = X->rows, m = Xs->rows, pn = KR->pcols;
+    MGPI_REQUIRE(KR->cols == n && pn % COV_T == 0 && KR->prows >= pn + mgpi_roundup(m, COV_T) && KR->rows == pn + m,
+                 "mgpi_cov_riders_dev: KR must be a wide (pn + m) x n matrix (got %lld x %lld for n = %lld, m = %lld)", (long long)KR->rows,
+                 (long long)KR->cols, (long long)n, (long long)m);
+    mgpi_terms_dev tk, ts;
+    MGPI_TRY(mgpi_make_terms(kterms, nk, (int)X->cols, &tk));
+    MGPI_TRY(mgpi_make_terms(sterms, ns, (int)X->cols, &ts));
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    mgpi_mat_invalidate(KR);
+    MGPI_TRY(mgpi_launch_cov(ctx, ts, X->d, X->ld, n, pn, X->d, X->ld, n, pn, 1, 1, 1, KR->d, KR->ld));
+    return mgpi_launch_cov(ctx, tk, Xs->d, Xs->ld, m, KR->prows - pn, X->d, X->ld, n, pn, 0, 0, 0, KR->d + pn * KR->ld, KR->ld);
+}
+
 extern "C" int mgpi_cov_matrix(mgpi_ctx* ctx, const double* x1, int64_t n1, const double* x2, int64_t n2, int d,
                                const mgpi_kernel_desc* terms, int nterms, double* out) {
     MGPI_REQUIRE(ctx && x1 && out, "mgpi_cov_matrix: null pointer");

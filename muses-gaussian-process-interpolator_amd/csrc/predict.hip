@@ -242,6 +242,54 @@ __global__ void var_finish_kernel(mgpi_terms_dev t, const double* __restrict__ x
     var[i] = mgpi_cov_entry<D>(t, q, q) - s;
 }
 
+// sq[i] = sum_j V[i][j]^2, one wave per row (fixed order: lane partial sums over a stride of 64, then the shuffle tree)
+__global__ __launch_bounds__(256) void rowsq_kernel(const double* __restrict__ V, int64_t ldv, int64_t rows, int64_t cols, double* __restrict__ sq) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const double* row = V + r * ldv;
+    double s = 0.0;
+    for (int64_t j = 2 * lane; j < cols; j += 128) {
+        const double2 v = *reinterpret_cast<const double2*>(row + j);
+        s = fma(v.x, v.x, s);
+        s = fma(v.y, v.y, s);
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) sq[r] = s;
+}
+
+// posterior variance from the rider rows mgpi_posv_riders_dev left in KR (rows [pn, pn + m) = V^T):
+// var_i = k(x*_i, x*_i) - sum_j V^T[i][j]^2   - the diagonal of mgpi/interpolators.py:199
+extern "C" int mgpi_riders_var_dev(mgpi_ctx* ctx, const mgpi_mat* KR, const mgpi_mat* Xs, const mgpi_kernel_desc* terms, int nterms,
+                                   mgpi_mat* var) {
+    MGPI_REQUIRE(ctx && KR && Xs && var && terms, "mgpi_riders_var_dev: null pointer");
+    const int64_t pn = KR->pcols, m = Xs->rows;
+    MGPI_REQUIRE(KR->factored && KR->rows == pn + m && var->rows == m && var->ld == 1,
+                 "mgpi_riders_var_dev: KR must come from mgpi_posv_riders_dev with %lld rider rows", (long long)m);
+    mgpi_terms_dev t;
+    MGPI_TRY(mgpi_make_terms(terms, nterms, (int)Xs->cols, &t));
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    MGPI_TRY(mgpi_ensure_work(ctx, (size_t)m * sizeof(double)));
+    double* sq = ctx->work;
+    hipLaunchKernelGGL(rowsq_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, ctx->stream, KR->d + pn * KR->ld, KR->ld, m, pn, sq);
+    dim3 g2((unsigned)((m + 255) / 256));
+#define MGPI_RV_CASE(DV)                                                                                                      \
+    case DV:                                                                                                                  \
+        hipLaunchKernelGGL(var_finish_kernel<DV>, g2, dim3(256), 0, ctx->stream, t, Xs->d, Xs->ld, m, sq, 1, m, var->d);    \
+        break;
+    switch (t.d) {
+        MGPI_RV_CASE(1)
+        MGPI_RV_CASE(2)
+        MGPI_RV_CASE(3)
+        MGPI_RV_CASE(4)
+        default:
+            hipLaunchKernelGGL(var_finish_kernel<0>, g2, dim3(256), 0, ctx->stream, t, Xs->d, Xs->ld, m, sq, 1, m, var->d);
+    }
+#undef MGPI_RV_CASE
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" int mgpi_predict_var_dev(mgpi_ctx* ctx, const mgpi_mat* Xs, const mgpi_mat* X, const mgpi_kernel_desc* terms,
                                     int nterms, const mgpi_mat* L, int64_t m_slab, mgpi_mat* var) {
     MGPI_REQUIRE(ctx && Xs && X && L && var, "mgpi_predict_var_dev: null pointer");

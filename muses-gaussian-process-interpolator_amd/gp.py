@@ -22,6 +22,7 @@ the matrix tile by tile (mgpi_cov_matrix_dev).  All O(N^2) and O(N^3) arithmetic
 libmgpi_hip.so; there is no numpy fallback.
 """
 import ctypes
+import os
 import time
 
 import numpy as np
@@ -70,10 +71,24 @@ class _Stage(object):
             print('    time : %.6f sec' % (time.time() - self.t0))
 
 
+def riders_pay(n, m):
+    """should m query points ride through the factorisation of an n-point GP (mgpi_posv_riders_dev)?  Measured on MI355X
+    (profiles/r03_riders_ab.md): up to N ~ 16k the factorisation is bound by its panel chain and the riders' N^2 M flops hide
+    beside it (C2, N = 8192, M = 4096: step 14.03 -> 13.07 ms); at N = 32768 the chip is busy with the trailing update anyway
+    (261.0 -> 259.2 ms, and the dominant kernel shares the GPU with more look-ahead work), so the two-pass form stays there.
+    MGPI_RIDERS=0 / 1 forces either form, MGPI_RIDERS_MAX_N moves the threshold."""
+    forced = os.environ.get('MGPI_RIDERS')
+    if m < 128 or m > n:
+        return False
+    if forced is not None:
+        return forced != '0'
+    return n <= int(os.environ.get('MGPI_RIDERS_MAX_N', '16384'))
+
+
 class FittedGP(object):
     """x, the Cholesky factor of K(x,x; kernel+nugget) and (optionally) alpha, resident in HBM"""
 
-    def __init__(self, ctx, source_x, kernel_terms, solve_terms, stage=None, source_f=None):
+    def __init__(self, ctx, source_x, kernel_terms, solve_terms, stage=None, source_f=None, riders_x=None):
         self.ctx = ctx
         self.lib = ctx.lib
         x = _points(source_x)
@@ -83,10 +98,14 @@ class FittedGP(object):
         self._kdesc = _lib.make_terms(self.kernel_terms)
         self._sdesc = _lib.make_terms(self.solve_terms)
         self.X = _lib.DeviceMatrix.from_host(ctx, x)
-        self.L = _lib.DeviceMatrix(ctx, self.n, self.n, wide=True)
         self.alpha = None
         self.logdet = None
+        self.riders = None             # (XS, KR) when query points rode through the factorisation (condition_diag)
         stage = stage or _Stage(ctx, False)
+        if riders_x is not None:
+            self._fit_with_riders(stage, source_f, riders_x)
+            return
+        self.L = _lib.DeviceMatrix(ctx, self.n, self.n, wide=True)
 
         stage.begin('constructing %d x %d source-source covariance matrix' % (self.n, self.n))
         # lower tiles only: the factorisation never reads the strict upper triangle
@@ -106,6 +125,41 @@ class FittedGP(object):
             _lib.check(self.lib.mgpi_posv_dev(ctx.handle, self.L.handle, self.alpha.handle, ctypes.byref(logdet)))
         self.logdet = logdet.value
         stage.end()
+
+    def _fit_with_riders(self, stage, source_f, riders_x):
+        """condition()'s three steps fused (mgpi_cov_riders_dev / mgpi_posv_riders_dev): K(x*, x) sits below K as extra rows and
+        comes out of the factorisation as V^T = K* L^-T - the forward solve of the posterior variance done by the panels'
+        substitutions and inside the trailing-update launches, not as a blocked triangular solve of its own afterwards"""
+        ctx, lib = self.ctx, self.lib
+        XS = self._targets(riders_x)
+        pn = (self.n + 127) // 128 * 128
+        KR = _lib.DeviceMatrix(ctx, pn + XS.rows, self.n, wide=True)
+        stage.begin('constructing %d x %d source-source covariance matrix' % (self.n, self.n))
+        _lib.check(lib.mgpi_cov_riders_dev(ctx.handle, self.X.handle, XS.handle, self._kdesc[0], self._kdesc[1], self._sdesc[0],
+                                           self._sdesc[1], KR.handle))
+        stage.end()
+        stage.begin('inverting source-source covariance matrix')
+        logdet = ctypes.c_double(0.0)
+        bh = None
+        if source_f is not None:
+            f = _lib.as_f64(source_f).reshape(-1)
+            assert len(f) == self.n, 'source_f has %d entries for %d source points' % (len(f), self.n)
+            self.alpha = _lib.DeviceMatrix.from_host(ctx, f)
+            bh = self.alpha.handle
+        _lib.check(lib.mgpi_posv_riders_dev(ctx.handle, KR.handle, bh, ctypes.byref(logdet)))
+        self.logdet = logdet.value
+        stage.end()
+        h = _lib._vp()
+        _lib.check(lib.mgpi_mat_square_view(KR.handle, ctypes.byref(h)))
+        self.L = _lib.DeviceMatrix(ctx, self.n, self.n, handle=h, parent=KR)      # the factor, for everything that takes L
+        self.riders = (XS, KR)
+
+    def riders_var_dev(self):
+        """posterior variance at the points that rode through the factorisation"""
+        XS, KR = self.riders
+        out = _lib.DeviceMatrix(self.ctx, XS.rows, 1)
+        _lib.check(self.lib.mgpi_riders_var_dev(self.ctx.handle, KR.handle, XS.handle, self._kdesc[0], self._kdesc[1], out.handle))
+        return out
 
     # alpha = K^-1 f
     def solve(self, source_f):
@@ -180,18 +234,20 @@ class Interpolator(HyperParameterSearch):
 
     #--- device-resident fit (additive)
 
-    def fit(self, source_x, source_f=None, verbose=False):
-        """build + factor K(x,x; kernel+nugget) on the GPU and (if source_f is given) solve for alpha"""
+    def fit(self, source_x, source_f=None, verbose=False, riders_x=None):
+        """build + factor K(x,x; kernel+nugget) on the GPU and (if source_f is given) solve for alpha.
+        riders_x: query points whose K(x*, x) rides through the factorisation (FittedGP.riders_var_dev gives their variance)"""
         stage = _Stage(self.context, verbose)
-        gp = FittedGP(self.context, source_x, _flatten(self.kernel), _flatten(self.kernel, self.nugget), stage=stage, source_f=source_f)
+        gp = FittedGP(self.context, source_x, _flatten(self.kernel), _flatten(self.kernel, self.nugget), stage=stage, source_f=source_f,
+                      riders_x=riders_x)
         if source_f is not None:
             stage.begin('compressing observations')       # the banner of interpolators.py:98; the solve rode along with the
             stage.end()                                    # factorisation above (mgpi_posv_dev), nothing is left to do here
         return gp
 
-    def _fit_checked(self, source_x, source_f, verbose):
+    def _fit_checked(self, source_x, source_f, verbose, riders_x=None):
         try:
-            return self.fit(source_x, source_f, verbose=verbose)
+            return self.fit(source_x, source_f, verbose=verbose, riders_x=riders_x)
         except _lib.NotPositiveDefinite as err:
             # the reference's inv() raises LinAlgError on a singular K; a Cholesky also rejects
             # indefinite K, which inv() would silently accept (SURVEY.md section 0)
@@ -307,15 +363,19 @@ class Interpolator(HyperParameterSearch):
 
     def condition_diag(self, target_x, source_x, source_f, verbose=False, m_slab=0):
         """additive: mean (M,) and pointwise variance (M,) = diag of condition()'s covariance, without
-        ever forming the M x M matrix"""
-        gp = self._fit_checked(source_x, source_f, verbose)
+        ever forming the M x M matrix.  While the queries are no more than the sources (and no slab size is asked for) they
+        RIDE through the factorisation (FittedGP._fit_with_riders): one pass builds, factors and forward-solves - where that
+        pays (riders_pay); otherwise the factor is reused slab by slab (mgpi_predict_var_dev)."""
+        xs = _points(target_x)
+        ride = m_slab == 0 and riders_pay(len(_points(source_x)), len(xs))
+        gp = self._fit_checked(source_x, source_f, verbose, riders_x=xs if ride else None)
         stage = _Stage(self.context, verbose)
-        XS = gp._targets(target_x)
+        XS = gp.riders[0] if ride else gp._targets(xs)
         stage.begin('computing conditioned mean')
         mean = gp.mean_dev(XS)
         stage.end()
         stage.begin('computing conditioned variance')
-        var = gp.var_dev(XS, m_slab=m_slab)
+        var = gp.riders_var_dev() if ride else gp.var_dev(XS, m_slab=m_slab)
         stage.end()
         return mean.to_host().reshape(-1), var.to_host().reshape(-1)
 

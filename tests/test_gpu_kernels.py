@@ -146,6 +146,39 @@ def test_posv_is_potrf_then_potrs(ctx, n):
         assert err.value.pivot == 1235
 
 
+@pytest.mark.parametrize('n,m', [(300, 130), (1700, 128), (1700, 1000), (5000, 700), (8192, 4096), (16500, 1500)])
+def test_riders_give_the_variance_of_the_two_pass_form(n, m, monkeypatch):
+    """condition_diag with the queries RIDING through the factorisation (K* below K: solved by the panels' substitutions,
+    updated inside the trailing-update launches; mgpi_posv_riders_dev) against the two-pass form (factor, then the blocked
+    multi-rhs solve of mgpi_predict_var_dev) and against the oracle's LAPACK statement: same alpha bit for bit (the square part
+    sees the same operations), mean identical, variance to 1e-11 of the prior variance [r3].  Sizes: single panel, one-panel
+    tail, look-ahead panels, C2 with its 4096 queries, merged trailing update; n and m off the 128 grid."""
+    rng = np.random.default_rng(n + m)
+    x = rng.random((n, 3))
+    f = np.sin(3 * x[:, 0]) + x[:, 1] * x[:, 2]
+    xs = rng.random((m, 3))
+    xs[:3] = x[:3]                                           # queries on sources
+    it = mgpi.Interpolator(mgpi.SquaredExponentialKernel(1.0, 0.2, 0.2, 0.2), nugget=mgpi.WhiteNoiseKernel(1e-2))
+    from mgpi_amd.gp import riders_pay
+    monkeypatch.delenv('MGPI_RIDERS', raising=False)
+    assert riders_pay(8192, 4096) and not riders_pay(32768, 4096) and not riders_pay(8192, 100) and not riders_pay(1000, 2000)
+    monkeypatch.setenv('MGPI_RIDERS', '1')
+    mean_r, var_r = it.condition_diag(xs, x, f)
+    gp = it.fit(x, f, riders_x=xs)
+    alpha_r = gp.alpha.to_host().reshape(-1)
+    var_again = gp.variance(xs)                              # the factor inside the riders matrix serves the two-pass entry too
+    monkeypatch.setenv('MGPI_RIDERS', '0')
+    mean_2, var_2 = it.condition_diag(xs, x, f)
+    alpha_2 = it.compress(x, f)
+    assert np.array_equal(alpha_r, alpha_2) and np.array_equal(mean_r, mean_2)
+    assert np.max(np.abs(var_r - var_2)) < 1e-11 and np.max(np.abs(var_again - var_2)) < 1e-13
+    assert np.all(var_r > -1e-12) and np.all(var_r[:3] < 1.1e-4)
+    if n <= 5000:
+        kernel, nugget = [oracle.term_se(1.0, 0.2, 0.2, 0.2)], [oracle.term_white(1e-2)]
+        L = oracle.cholesky_lower(oracle.x2cov_chunked(kernel + nugget, x, x, rows=max(1, 262144 // n)))
+        assert np.max(np.abs(var_r - oracle.diag_variance_cholesky(kernel, L, xs, x))) < 1e-10
+
+
 def test_c_abi_host_entry_points(ctx):
     """the host-pointer entry points a ctypes binding at the reference's call sites would use"""
     rng = np.random.default_rng(21)
