@@ -778,40 +778,55 @@ class DistributedGP(object):
         use_inv = os.environ.get('MGPI_DIST_VAR_DINV', '1') != '0'
         if use_inv:
             self._ensure_dinv()
-        vk = be.alloc(nb, per, zero=False)
+        # Block rows are solved one at a time; the rows behind a SUPER-PANEL of the factorisation are updated once, with all of its
+        # block columns at a time (the slabs the factorisation left side by side in row_panels: contraction 2 nb while many rows
+        # trail, as in the factorisation itself) - half the update launches, each at the longer contraction's rate.
+        supers = self.super_panels_
+        wmax = max(len(b) for b in supers)
+        vks = be.alloc(wmax * nb, per, zero=False)               # the solved block rows of one super-panel, stacked
         lkk = be.alloc(nb, nb, zero=False)
-        for k in range(self.nblk):
-            pk, qk = k % g.P, k % g.Q
-            kr, kc = k // g.P, k // g.Q
-            i0 = self._first_local(self.row_blocks, k)
-            mt = self.mloc - i0 * nb
-            # diagonal block to the whole process row pk, which solves its slice of block row k of V.  With the
-            # inverse diagonal blocks (default) what travels is -(L_kk)^-1 and the solve is one gemm instead of the
-            # 8-step substitution chain, which would otherwise sit on the critical path of every block step
-            if g.p == pk:
-                Vk = W(V, kr * nb, nb)
-                if use_inv:
-                    inv = lkk
-                    if g.Q > 1 or g.always:
-                        if g.q == qk:
-                            be.copy(lkk, self._dinv[k])
-                        g.bcast_row(be, lkk, qk)
+        for si, blocks in enumerate(supers):
+            for h, k in enumerate(blocks):
+                pk, qk = k % g.P, k % g.Q
+                kr, kc = k // g.P, k // g.Q
+                vk = W(vks, h * nb, nb)
+                if g.p == pk:
+                    Vk = W(V, kr * nb, nb)
+                    # bring block row k up to date with the earlier block rows of this super-panel: L[k][k'] is the block row
+                    # I = k of the row panel of step k'
+                    for hh in range(h):
+                        r0, c0 = self._row_panel_view[blocks[hh]]
+                        skip = kr - self._first_local(self.row_blocks, blocks[hh])      # local block rows between k' and k
+                        be.gemm_nn(Vk, W(self.row_panels, r0 + skip * nb, nb, c0, nb), W(vks, hh * nb, nb))
+                    # diagonal block to the whole process row pk, which solves its slice of block row k of V.  With the
+                    # inverse diagonal blocks (default) what travels is -(L_kk)^-1 and the solve is one gemm instead of the
+                    # 8-step substitution chain, which would otherwise sit on the critical path of every block step
+                    if use_inv:
+                        inv = lkk
+                        if g.Q > 1 or g.always:
+                            if g.q == qk:
+                                be.copy(lkk, self._dinv[k])
+                            g.bcast_row(be, lkk, qk)
+                        else:
+                            inv = self._dinv[k]                                  # nobody to send it to: use it where it is
+                        be.gemm_nn_neg(vk, inv, Vk)                              # -(-(L_kk)^-1) V_k, straight into the buffer
+                        be.copy(Vk, vk)                                          # that is broadcast next
                     else:
-                        inv = self._dinv[k]                                      # nobody to send it to: use it where it is
-                    be.gemm_nn_neg(vk, inv, Vk)                                  # -(-(L_kk)^-1) V_k, straight into the buffer
-                    be.copy(Vk, vk)                                              # that is broadcast next
-                else:
-                    if g.q == qk:
-                        be.copy(lkk, W(A, kr * nb, nb, kc * nb, nb))
-                    g.bcast_row(be, lkk, qk)
-                    be.trsm_left(lkk, Vk)
-                    be.copy(vk, Vk)
-            g.bcast_col(be, vk, pk)
-            # panel blocks L[I][k], I > k: every rank kept its row panel of step k from the factorisation
-            # (self.row_panels), so the factor is NOT broadcast a second time
+                        if g.q == qk:
+                            be.copy(lkk, W(A, kr * nb, nb, kc * nb, nb))
+                        g.bcast_row(be, lkk, qk)
+                        be.trsm_left(lkk, Vk)
+                        be.copy(vk, Vk)
+                g.bcast_col(be, vk, pk)
+            # the rows behind the super-panel: every rank kept its row panels from the factorisation (self.row_panels), so the
+            # factor is NOT broadcast a second time
+            kl = blocks[-1]
+            i0 = self._first_local(self.row_blocks, kl)
+            mt = self.mloc - i0 * nb
             if mt > 0:
-                r0, c0 = self._row_panel_view[k]
-                be.gemm_nn(W(V, i0 * nb, mt), W(self.row_panels, r0, mt, c0, nb), vk)
+                i00 = self._first_local(self.row_blocks, blocks[0])
+                width = len(blocks) * nb
+                be.gemm_nn(W(V, i0 * nb, mt), W(self.row_panels, self._slab_offset[si] + (i0 - i00) * nb, mt, 0, width), W(vks, 0, width))
         sq_dev = be.alloc(per, 1)
         be.colsq(V, sq_dev)
         if g.P > 1 or g.always:
