@@ -234,6 +234,17 @@ int  mgpi_ctx_status_reset(mgpi_ctx* ctx);
 int  mgpi_ctx_status_read(mgpi_ctx* ctx, int64_t* pivot, double* logdiag);      /* synchronises ctx's stream */
 /* order two contexts of one device: what `signaler` has queued so far precedes what `waiter` queues from now on */
 int  mgpi_ctx_wait(mgpi_ctx* waiter, mgpi_ctx* signaler);
+/* the merged form of the driver's trailing update: mgpi_gemm_nt_stair_merged_dev updates the first `first_cols` local block columns
+ * of C first, stores them write-through and counts their tiles on ctx's progress counter (*live_tiles = how far it moves);
+ * mgpi_ctx_wait_count makes another context of the same device wait for a count instead of a kernel boundary, so that the next
+ * super-panel is factored while the rest of the same launch runs; mgpi_ctx_count_reset zeroes the counter (once per factorisation);
+ * mgpi_ctx_streams_overlap asks the device whether kernels of the two contexts run side by side at all (bounded handshake) -
+ * where they do not (profilers, serialising debug switches) the driver keeps the two-launch form. */
+int  mgpi_gemm_nt_stair_merged_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* B, mgpi_mat* C, int P, int p, int Q, int q,
+                                   int bi0, int bj0, int nb, int first_cols, int64_t* live_tiles);
+int  mgpi_ctx_wait_count(mgpi_ctx* waiter, mgpi_ctx* owner, int64_t target);
+int  mgpi_ctx_count_reset(mgpi_ctx* ctx);
+int  mgpi_ctx_streams_overlap(mgpi_ctx* a, mgpi_ctx* b, int* yes);
 /* from now on this context's launches go to its high-priority stream (the look-ahead context of the driver: its panels and
  * broadcasts must not queue behind the main context's trailing update); call on an idle context */
 int  mgpi_ctx_prefer_high_priority(mgpi_ctx* ctx);

@@ -105,6 +105,11 @@ _SIGNATURES = {
     'mgpi_trsv_dev': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
     'mgpi_gemv_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int]),
     'mgpi_ctx_prefer_high_priority': (ctypes.c_int, [_vp]),
+    'mgpi_gemm_nt_stair_merged_dev': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_int64)]),
+    'mgpi_ctx_wait_count': (ctypes.c_int, [_vp, _vp, c_int64]),
+    'mgpi_ctx_count_reset': (ctypes.c_int, [_vp]),
+    'mgpi_ctx_streams_overlap': (ctypes.c_int, [_vp, _vp, ctypes.POINTER(ctypes.c_int)]),
     'mgpi_potrf_enqueue_dev': (ctypes.c_int, [_vp, _vp, c_int64, _vp]),
     'mgpi_potrf_panel_enqueue_dev': (ctypes.c_int, [_vp, _vp, c_int64, _vp]),
     'mgpi_ctx_status_reset': (ctypes.c_int, [_vp]),

@@ -14,11 +14,17 @@ fails here instead.  Usage: check_isa.py build/gemm.s
 import re
 import sys
 
-MERGED = '_Z20gemm_f64_pipe_kernelILb0ELb1ELb0ELb1EE'      # <BKM=false, LOWER=true, ZEROC=false, MERGED=true>
+MERGED_KERNELS = ['_Z20gemm_f64_pipe_kernelILb0ELb1ELb0ELb1EE',      # <BKM=false, LOWER=true, ZEROC=false, MERGED=true>: single GPU
+                  '_Z20gemm_f64_pipe_kernelILb0ELb0ELb0ELb1EE']      # <.., LOWER=false, .., MERGED=true>: the driver's staircase
 
 
 def main(path):
     text = open(path).read()
+    for name in MERGED_KERNELS:
+        check(text, name, path)
+
+
+def check(text, MERGED, path):
     m = re.search(r'^(%s\w*):.*?^\s*\.amdhsa_kernel \1' % MERGED, text, re.S | re.M)
     if not m:
         sys.exit('check_isa: the merged trailing-update kernel (%s...) is not in %s' % (MERGED, path))
@@ -32,7 +38,7 @@ def main(path):
     between = body[wt[-1]:adds[0]]
     if adds[0] < wt[-1] or not any(re.search(r's_waitcnt\s+vmcnt\(0\)', l) for l in between) or not any('s_barrier' in l for l in between):
         sys.exit('check_isa: the counter increment must follow the write-through stores, an s_waitcnt vmcnt(0) and a barrier')
-    print('check_isa: merged trailing update: 64 sc1 stores -> s_waitcnt vmcnt(0) -> s_barrier -> global_atomic_add  OK')
+    print('check_isa: %s: 64 sc1 stores -> s_waitcnt vmcnt(0) -> s_barrier -> global_atomic_add  OK' % MERGED)
 
 
 if __name__ == '__main__':

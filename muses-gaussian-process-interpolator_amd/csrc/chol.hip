@@ -400,26 +400,58 @@ static bool serialising_environment() {
     return false;
 }
 
-// 1: the two streams of ctx overlap; 0: they do not (or the question could not be asked).  Asked once per context.
-static int streams_overlap(mgpi_ctx* ctx) {
-    if (ctx->streams_overlap >= 0) return ctx->streams_overlap;
-    ctx->streams_overlap = 0;
-    if (!ctx->stream2 || serialising_environment()) return 0;
+// the handshake between stream a (which owns the scratch and the event) and stream b: 1 = the two kernels were resident together
+static int overlap_handshake(mgpi_ctx* ctx, hipStream_t a, hipStream_t b) {
+    if (serialising_environment()) return 0;
     unsigned* flags = reinterpret_cast<unsigned*>(ctx->d_scal + 8072);     // two handshake words and the verdict
     int* ok = reinterpret_cast<int*>(flags + 2);
-    if (hipMemsetAsync(flags, 0, 4 * sizeof(unsigned), ctx->stream) != hipSuccess) return 0;
-    if (hipEventRecord(ctx->ev_join, ctx->stream) != hipSuccess || hipStreamWaitEvent(ctx->stream2, ctx->ev_join, 0) != hipSuccess) return 0;
-    hipLaunchKernelGGL(overlap_probe_kernel, dim3(1), dim3(64), 0, ctx->stream, flags, flags + 1, ok);
-    hipLaunchKernelGGL(overlap_probe_kernel, dim3(1), dim3(64), 0, ctx->stream2, flags + 1, flags, ok);
+    if (hipMemsetAsync(flags, 0, 4 * sizeof(unsigned), a) != hipSuccess) return 0;
+    if (hipEventRecord(ctx->ev_join, a) != hipSuccess || hipStreamWaitEvent(b, ctx->ev_join, 0) != hipSuccess) return 0;
+    hipLaunchKernelGGL(overlap_probe_kernel, dim3(1), dim3(64), 0, a, flags, flags + 1, ok);
+    hipLaunchKernelGGL(overlap_probe_kernel, dim3(1), dim3(64), 0, b, flags + 1, flags, ok);
     int both = 0;
-    if (hipEventRecord(ctx->ev_join, ctx->stream2) != hipSuccess || hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0) != hipSuccess ||
-        hipMemcpyAsync(&both, ok, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    if (hipEventRecord(ctx->ev_join, b) != hipSuccess || hipStreamWaitEvent(a, ctx->ev_join, 0) != hipSuccess ||
+        hipMemcpyAsync(&both, ok, sizeof(int), hipMemcpyDeviceToHost, a) != hipSuccess || hipStreamSynchronize(a) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
-    ctx->streams_overlap = both == 2 ? 1 : 0;
+    return both == 2 ? 1 : 0;
+}
+
+// 1: the two streams of ctx overlap; 0: they do not (or the question could not be asked).  Asked once per context.
+static int streams_overlap(mgpi_ctx* ctx) {
+    if (ctx->streams_overlap >= 0) return ctx->streams_overlap;
+    ctx->streams_overlap = ctx->stream2 ? overlap_handshake(ctx, ctx->stream, ctx->stream2) : 0;
     return ctx->streams_overlap;
+}
+
+// the same question for the streams of TWO contexts of one device (the multi-GPU driver's main and look-ahead contexts)
+extern "C" int mgpi_ctx_streams_overlap(mgpi_ctx* a, mgpi_ctx* b, int* yes) {
+    MGPI_REQUIRE(a && b && yes, "mgpi_ctx_streams_overlap: null pointer");
+    MGPI_REQUIRE(a->device == b->device, "mgpi_ctx_streams_overlap: contexts on different devices");
+    MGPI_HIP_TRY(hipSetDevice(a->device));
+    *yes = (a == b) ? 0 : overlap_handshake(a, a->stream, b->stream);
+    return 0;
+}
+
+// progress counter of ctx's merged trailing updates (mgpi_gemm_nt_stair_merged_dev): back to zero, on ctx's stream
+extern "C" int mgpi_ctx_count_reset(mgpi_ctx* ctx) {
+    MGPI_REQUIRE(ctx != nullptr, "mgpi_ctx_count_reset: null ctx");
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    MGPI_HIP_TRY(hipMemsetAsync(ctx->d_scal + 8064, 0, sizeof(unsigned), ctx->stream));
+    return 0;
+}
+
+// what `waiter` enqueues from now on starts once `owner`'s progress counter has reached `target` (one sleeping wave on waiter's
+// stream; bounded: if the count never comes the waiter's status word turns negative and its next status read fails)
+extern "C" int mgpi_ctx_wait_count(mgpi_ctx* waiter, mgpi_ctx* owner, int64_t target) {
+    MGPI_REQUIRE(waiter && owner, "mgpi_ctx_wait_count: null ctx");
+    MGPI_REQUIRE(waiter->device == owner->device && target >= 0 && target < ((int64_t)1 << 31), "mgpi_ctx_wait_count: bad argument");
+    MGPI_HIP_TRY(hipSetDevice(waiter->device));
+    hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(64), 0, waiter->stream, reinterpret_cast<const unsigned*>(owner->d_scal + 8064),
+                       (unsigned)target, waiter->d_info);
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 // ---- the factorisation ----------------------------------------------------------------------------------

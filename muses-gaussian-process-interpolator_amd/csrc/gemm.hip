@@ -268,8 +268,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_pipe_kernel(int64_t k, const 
     constexpr int STAGE = GA::doubles + GB::doubles;
 
     int ti, tj;
-    if constexpr (MERGED) {
+    if constexpr (MERGED && LOWER) {
         merged_decode(blockIdx.x, tiles_m, st.mg_cw, st.mg_ncol, ntiles, ti, tj);
+    } else if constexpr (MERGED) {          // the staircase of the multi-GPU driver, next super-panel's block columns first
+        if (!gemm_stair_merged_decode(st, blockIdx.x, ntiles, tiles_m, ti, tj)) return;
     } else {
         const int64_t bid = gemm_xcd_remap(blockIdx.x, ntiles);
         if (!LOWER && st.on) {
@@ -552,6 +554,37 @@ extern "C" int mgpi_gemm_nn_neg_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi
     const int rc = mgpi_gemm_nn_dev(ctx, A, B, C);
     ctx->gemm_zero_c = 0;
     return rc;
+}
+
+// the merged form of mgpi_gemm_nt_stair_dev below: the first `first_cols` local block columns of C (the next super-panel's, which
+// the look-ahead context factors next) are updated first, stored write-through and counted on ctx's progress counter - the
+// look-ahead context waits for the count (mgpi_ctx_wait_count) instead of running those columns as a gemm of its own beside this
+// one.  *live_tiles: how far the counter moves (the tiles of those columns on/below the global diagonal).
+extern "C" int mgpi_gemm_nt_stair_merged_dev(mgpi_ctx* ctx, const mgpi_mat* A, const mgpi_mat* B, mgpi_mat* C, int P, int p, int Q,
+                                             int q, int bi0, int bj0, int nb, int first_cols, int64_t* live_tiles) {
+    MGPI_REQUIRE(ctx && A && B && C && live_tiles, "mgpi_gemm_nt_stair_merged_dev: null pointer");
+    MGPI_REQUIRE(A->cols == B->cols && C->rows == A->rows && C->cols == B->rows, "mgpi_gemm_nt_stair_merged_dev: shapes do not conform");
+    MGPI_REQUIRE(P >= 1 && Q >= 1 && p >= 0 && p < P && q >= 0 && q < Q && nb >= 128 && nb % 128 == 0 && first_cols >= 1,
+                 "mgpi_gemm_nt_stair_merged_dev: bad grid description");
+    const int64_t m = C->prows, n = C->pcols, k = A->pcols < B->pcols ? A->pcols : B->pcols;
+    MGPI_REQUIRE(m % 128 == 0 && n % 128 == 0 && k % GEMM_BK == 0 && (int64_t)first_cols * nb < n,
+                 "mgpi_gemm_nt_stair_merged_dev: extents must be tile multiples and the first columns a proper part");
+    MGPI_REQUIRE(((uintptr_t)A->d % 16 == 0) && ((uintptr_t)B->d % 16 == 0) && A->ld % 2 == 0 && B->ld % 2 == 0,
+                 "mgpi_gemm_nt_stair_merged_dev: operands must be 16-byte aligned with even leading dimensions");
+    MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    gemm_stair st = no_stair();
+    const int tm = (int)(m / 128), tn = (int)(n / 128);
+    *live_tiles = 0;
+    const int64_t total = gemm_stair_fill_merged(st, tm, tn, P, p, Q, q, bi0, bj0, nb / 128, first_cols * (nb / 128), live_tiles);
+    MGPI_REQUIRE(total >= 0, "mgpi_gemm_nt_stair_merged_dev: local trailing matrix has too many tile rows (%d)", tm);
+    if (total == 0) return 0;
+    st.mg_counter = reinterpret_cast<unsigned*>(ctx->d_scal + 8064);
+    mgpi_prof_begin(ctx, 0);
+    hipLaunchKernelGGL((gemm_f64_pipe_kernel<false, false, false, true>), dim3((unsigned)total), dim3(256), 0, ctx->stream, k, A->d, A->ld, B->d,
+                       B->ld, C->d, C->ld, tm, tn, total, st);
+    mgpi_prof_end(ctx, 0);
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 // C -= A B^T restricted to the tiles on/below the GLOBAL diagonal of a 2-D block-cyclic matrix: C is this rank's

@@ -86,6 +86,36 @@ int main() {
                           (long long)gr, (long long)gc, P, Q, p, q);
                 }
             }
+    // merged staircase (the driver's trailing update with the next super-panel's block columns first): region 1 = the enumerated
+    // tiles of the first cw tile columns, the two regions together exactly the plain staircase's live tiles, live1 = region 1's
+    for (int P = 1; P <= 3; ++P) for (int Q = 1; Q <= 4; ++Q) for (int p = 0; p < P; ++p) for (int q = 0; q < Q; ++q)
+        for (int tpb = 1; tpb <= 4; tpb *= 2) for (int bi0 = 0; bi0 <= 2; ++bi0) for (int bj0 = 0; bj0 <= 1; ++bj0)
+            for (int mb = 1; mb <= 5; mb += 2) for (int nbk = 2; nbk <= 6; nbk += 2) for (int fc = 1; fc < nbk && fc <= 2; ++fc) {
+                const int tm = mb * tpb, tn = nbk * tpb, cw = fc * tpb;
+                gemm_stair st, plain;
+                int64_t live1 = -1;
+                const int64_t total = gemm_stair_fill_merged(st, tm, tn, P, p, Q, q, bi0, bj0, tpb, cw, &live1);
+                const int64_t total_plain = gemm_stair_fill(plain, tm, tn, P, p, Q, q, bi0, bj0, tpb);
+                CHECK(total == total_plain && st.mg_ncol == st.prefix[st.nbands] && st.mg_ncol + st.prefix2[st.nbands] == total, "merged staircase totals");
+                std::set<std::pair<int, int>> live, want;
+                int64_t counted = 0;
+                for (int64_t b = 0; b < total; ++b) {
+                    int ti, tj;
+                    const bool ok = gemm_stair_merged_decode(st, b, total, tm, ti, tj);
+                    CHECK(ti >= 0 && ti < tm && tj >= 0 && tj < tn, "merged staircase decode out of range (%d, %d) of %d x %d", ti, tj, tm, tn);
+                    CHECK((tj < cw) == (b < st.mg_ncol), "merged staircase: tile (%d, %d) in the wrong region (cw %d)", ti, tj, cw);
+                    if (ok) {
+                        CHECK(live.insert({ti, tj}).second, "merged staircase repeats (%d, %d)", ti, tj);
+                        if (b < st.mg_ncol) ++counted;
+                    }
+                }
+                for (int64_t b = 0; b < total_plain; ++b) {
+                    int ti, tj;
+                    if (gemm_stair_decode(plain, b, tm, ti, tj)) want.insert({ti, tj});
+                }
+                CHECK(live == want, "merged staircase covers other tiles than the plain one (P%d Q%d p%d q%d)", P, Q, p, q);
+                CHECK(counted == live1, "merged staircase: %lld live tiles in the first region, the host counted %lld", (long long)counted, (long long)live1);
+            }
     // merged trailing update: the first region is exactly the first cw tile columns, the two regions together the whole triangle
     for (int tm = 2; tm <= 45; ++tm)
         for (int cw = 1; cw <= 8 && cw < tm; ++cw) {

@@ -77,6 +77,7 @@ struct gemm_stair {
     int on, P, p, Q, q, bi0, bj0, tpb;
     int nbands;
     int prefix[GEMM_STAIR_BANDS + 1];
+    int prefix2[GEMM_STAIR_BANDS + 1];   // merged staircase: prefix = the first mg_cw tile columns (region 1), prefix2 = the rest
     int zero_c;          // the accumulators start from 0 instead of the C tile: C = -A B (rides along in this by-value argument)
     // merged trailing update (chol.hip): the first mg_ncol workgroups own the tiles of the first mg_cw tile columns - the next
     // panel's block column - and each bumps *mg_counter once its tile is stored
@@ -105,6 +106,64 @@ inline int64_t gemm_stair_fill(gemm_stair& st, int tm, int tn, int P, int p, int
     return total;
 }
 
+// XCD-aware order: workgroups b, b + 8, .. share an XCD; each XCD gets a contiguous run of the tile list
+MGPI_HD int64_t gemm_xcd_remap(int64_t bid, int64_t ntiles) {
+    const int64_t q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, loc = bid / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+// Merged staircase (the multi-GPU driver's trailing update with the next super-panel's local block columns first): the same
+// enumeration cut at tile column cw - region 1 = the columns [0, cw) of every band, region 2 = the rest - each region dealt
+// to the XCDs on its own, region 1 dispatched (hence finished) first.  Returns the total number of enumerated tiles, sets
+// st.mg_ncol (enumerated tiles of region 1) and *live1 (those of them on/below the global diagonal: what the counter reaches).
+inline int64_t gemm_stair_fill_merged(gemm_stair& st, int tm, int tn, int P, int p, int Q, int q, int bi0, int bj0, int tpb, int cw,
+                                      int64_t* live1) {
+    st.on = 1; st.P = P; st.p = p; st.Q = Q; st.q = q; st.bi0 = bi0; st.bj0 = bj0; st.tpb = tpb;
+    st.nbands = (tm + GEMM_BAND - 1) / GEMM_BAND;
+    if (st.nbands > GEMM_STAIR_BANDS) return -1;
+    int64_t n1 = 0, n2 = 0, live = 0;
+    for (int b = 0; b < st.nbands; ++b) {
+        st.prefix[b] = (int)n1;
+        st.prefix2[b] = (int)n2;
+        const int rows = (tm - b * GEMM_BAND < GEMM_BAND) ? (tm - b * GEMM_BAND) : GEMM_BAND;
+        const int last = b * GEMM_BAND + rows - 1;
+        const int64_t gr = (int64_t)(p + P * (bi0 + last / tpb)) * tpb + last % tpb;
+        int cmax = 0;
+        while (cmax < tn && (int64_t)(q + Q * (bj0 + cmax / tpb)) * tpb + cmax % tpb <= gr) ++cmax;
+        const int c1 = cmax < cw ? cmax : cw;
+        n1 += (int64_t)rows * c1;
+        n2 += (int64_t)rows * (cmax - c1);
+        for (int r = 0; r < rows; ++r) {
+            const int ti = b * GEMM_BAND + r;
+            const int I = p + P * (bi0 + ti / tpb);
+            for (int tj = 0; tj < c1; ++tj) {
+                const int J = q + Q * (bj0 + tj / tpb);
+                if (!(I < J || (I == J && (ti % tpb) < (tj % tpb)))) ++live;
+            }
+        }
+    }
+    st.prefix[st.nbands] = (int)n1;
+    st.prefix2[st.nbands] = (int)n2;
+    st.mg_cw = cw;
+    st.mg_ncol = (int)n1;
+    if (live1) *live1 = live;
+    return n1 + n2;
+}
+
+MGPI_HD bool gemm_stair_merged_decode(const gemm_stair& st, int64_t bid, int64_t ntiles, int tiles_m, int& ti, int& tj) {
+    const bool first = bid < st.mg_ncol;
+    const int* pre = first ? st.prefix : st.prefix2;
+    const int64_t idx = first ? gemm_xcd_remap(bid, st.mg_ncol) : gemm_xcd_remap(bid - st.mg_ncol, ntiles - st.mg_ncol);
+    int band = 0;
+    while (band + 1 < st.nbands && pre[band + 1] <= idx) ++band;
+    const int within = (int)idx - pre[band];
+    const int rows = (tiles_m - band * GEMM_BAND < GEMM_BAND) ? (tiles_m - band * GEMM_BAND) : GEMM_BAND;
+    tj = within / rows + (first ? 0 : st.mg_cw);
+    ti = band * GEMM_BAND + within % rows;
+    const int I = st.p + st.P * (st.bi0 + ti / st.tpb), J = st.q + st.Q * (st.bj0 + tj / st.tpb);
+    return !(I < J || (I == J && (ti % st.tpb) < (tj % st.tpb)));
+}
+
 // staircase decode of one workgroup: false = the tile lies above the global diagonal (or outside) and is skipped
 MGPI_HD bool gemm_stair_decode(const gemm_stair& st, int64_t bid, int tiles_m, int& ti, int& tj) {
     int band = 0;
@@ -115,12 +174,6 @@ MGPI_HD bool gemm_stair_decode(const gemm_stair& st, int64_t bid, int tiles_m, i
     ti = band * GEMM_BAND + within - tj * rows;
     const int I = st.p + st.P * (st.bi0 + ti / st.tpb), J = st.q + st.Q * (st.bj0 + tj / st.tpb);
     return !(I < J || (I == J && (ti % st.tpb) < (tj % st.tpb)));
-}
-
-// XCD-aware order: workgroups b, b + 8, .. share an XCD; each XCD gets a contiguous run of the tile list
-MGPI_HD int64_t gemm_xcd_remap(int64_t bid, int64_t ntiles) {
-    const int64_t q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, loc = bid / 8;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
 // Merged trailing update: the lower triangle of a tm x tm tile grid in TWO regions, the first cw tile columns first.

@@ -312,6 +312,27 @@ class HipTileBackend(object):
         """the whole local trailing update of one block step in ONE launch: tiles above the global diagonal exit"""
         _lib.check(self.lib.mgpi_gemm_nt_stair_dev(self.ctx.handle, a.handle, b.handle, c.handle, P, p, Q, q, bi0, bj0, nb))
 
+    def gemm_nt_stair_merged(self, c, a, b, P, p, Q, q, bi0, bj0, nb, first_cols):
+        """the same update with the first `first_cols` local block columns first, stored write-through and counted on this
+        context's progress counter; returns how far the counter moves (wait_count is the other half)"""
+        live = _lib.c_int64(0)
+        _lib.check(self.lib.mgpi_gemm_nt_stair_merged_dev(self.ctx.handle, a.handle, b.handle, c.handle, P, p, Q, q, bi0, bj0, nb,
+                                                          int(first_cols), ctypes.byref(live)))
+        return int(live.value)
+
+    def count_reset(self):
+        _lib.check(self.lib.mgpi_ctx_count_reset(self.ctx.handle))
+
+    def wait_count(self, owner, target):
+        """what this backend enqueues from now on starts once `owner`'s progress counter has reached `target`"""
+        _lib.check(self.lib.mgpi_ctx_wait_count(self.ctx.handle, owner.ctx.handle, int(target)))
+
+    def overlaps(self, other):
+        """do kernels of this backend's stream and of `other`'s run side by side (bounded device handshake)?"""
+        yes = ctypes.c_int(0)
+        _lib.check(self.lib.mgpi_ctx_streams_overlap(self.ctx.handle, other.ctx.handle, ctypes.byref(yes)))
+        return bool(yes.value)
+
     def gemm_nn(self, c, a, b):
         _lib.check(self.lib.mgpi_gemm_nn_dev(self.ctx.handle, a.handle, b.handle, c.handle))
 
@@ -545,18 +566,24 @@ class DistributedGP(object):
                     wcol=W(bufs['wcol'], (j0 - j00) * nb, nt, 0, width) if nt > 0 else None,
                     i0=i0, j0=j0, mt=mt, nt=nt, kblocks=len(blocks))
 
-    def _update(self, pan, c_lo, c_hi, be):
+    def _update(self, pan, c_lo, c_hi, be, first_cols=0):
         """trailing update of the local block columns [c_lo, c_hi) with the panel(s) `pan` describes:
-        A[I][J] -= sum_k L[I][k] L[J][k]^T for the local blocks with I >= J.  One launch (staircase gemm)."""
+        A[I][J] -= sum_k L[I][k] L[J][k]^T for the local blocks with I >= J.  One launch (staircase gemm).
+        first_cols > 0: the merged form - those first columns first, counted; returns how far the progress counter moves."""
         g, nb = self.g, self.nb
         i0, j0 = pan['i0'], pan['j0']
         c_hi = min(c_hi, len(self.col_blocks))
         if pan['mt'] <= 0 or c_lo >= c_hi:
-            return
+            return 0
         W = be.window
         kw = pan['wrow'].cols if hasattr(pan['wrow'], 'cols') else pan['wrow'].shape[1]
-        be.gemm_nt_stair(W(self.A, i0 * nb, pan['mt'], c_lo * nb, (c_hi - c_lo) * nb), pan['wrow'],
-                         W(pan['wcol'], (c_lo - j0) * nb, (c_hi - c_lo) * nb, 0, kw), g.P, g.p, g.Q, g.q, i0, c_lo, nb)
+        live = 0
+        cwin = W(self.A, i0 * nb, pan['mt'], c_lo * nb, (c_hi - c_lo) * nb)
+        bwin = W(pan['wcol'], (c_lo - j0) * nb, (c_hi - c_lo) * nb, 0, kw)
+        if first_cols > 0:
+            live = be.gemm_nt_stair_merged(cwin, pan['wrow'], bwin, g.P, g.p, g.Q, g.q, i0, c_lo, nb, first_cols)
+        else:
+            be.gemm_nt_stair(cwin, pan['wrow'], bwin, g.P, g.p, g.Q, g.q, i0, c_lo, nb)
         flops = 0.0                                              # flop bookkeeping only (bench.py roofline)
         for jl in range(c_lo, c_hi):
             J = self.col_blocks[jl]
@@ -569,6 +596,7 @@ class DistributedGP(object):
             self.trailing_flops += flops                         # launches timed by the main context's profile slot 0
         else:
             self.column_flops += flops                           # next-panel column updates on the look-ahead stream
+        return live
 
     def factor(self, lookahead=None):
         """2-D block-cyclic right-looking Cholesky in super-panels.  With look-ahead (default; MGPI_DIST_LOOKAHEAD=0 turns it
@@ -604,6 +632,16 @@ class DistributedGP(object):
             self.row_panels = be.alloc(total, wmax, zero=False)
         side.status_reset()
         side.wait(be)                                           # the build (and the allocations' fills) precede the first panel
+        # Merged trailing update, as on one GPU (csrc/chol.hip): while at least merged_min_rows local rows trail, ONE launch
+        # updates the whole local trailing matrix - the next super-panel's local block columns first, stored write-through and
+        # counted - and the look-ahead context starts on that count while the rest of the same launch runs, instead of two
+        # launches side by side.  Only where the two contexts' kernels do overlap (bounded device handshake; not under
+        # counter collection or serialising debug switches); MGPI_DIST_MERGED=0 keeps the two launches.
+        merged = lookahead and os.environ.get('MGPI_DIST_MERGED', '1') != '0' and side is not be and be.overlaps(side)
+        merged_min = int(os.environ.get('MGPI_DIST_MERGED_MIN', 12288))
+        target = 0
+        if merged:
+            be.count_reset()
 
         ncols = len(self.col_blocks)
         pan = self._panel_super(0, side, bufs[0])
@@ -622,9 +660,13 @@ class DistributedGP(object):
             # for what the main stream had queued BEFORE (a): the rest of step s-1, which wrote the columns (b) touches.
             side.wait(be)
             nown = sum(1 for k in supers[s + 1] if k % g.Q == g.q)   # they are the first local trailing columns
-            self._update(pan, j0 + nown, ncols, be)
-            if nown:
-                self._update(pan, j0, j0 + nown, side)
+            if merged and nown and ncols - j0 > nown and pan['mt'] >= merged_min:
+                target += self._update(pan, j0, ncols, be, first_cols=nown)
+                side.wait_count(be, target)
+            else:
+                self._update(pan, j0 + nown, ncols, be)
+                if nown:
+                    self._update(pan, j0, j0 + nown, side)
             nxt_pan = self._panel_super(s + 1, side, bufs[(s + 1) % 2])
             be.wait(side)
             pan = nxt_pan

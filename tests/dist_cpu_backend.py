@@ -25,7 +25,11 @@ class NumpyTileBackend(object):
 
     # -- streams: on the CPU everything runs in program order
     def side_backend(self):
-        return self
+        # a second handle on the same state: the schedule takes its merged branch only when the look-ahead backend is a
+        # different object (two contexts on the GPU); everything runs in program order here either way
+        if getattr(self, '_side', None) is None:
+            self._side = _SideView(self)
+        return self._side
 
     def wait(self, other):
         pass
@@ -116,6 +120,20 @@ class NumpyTileBackend(object):
                 if I >= J:
                     c[bi * nb:(bi + 1) * nb, bj * nb:(bj + 1) * nb] -= a[bi * nb:(bi + 1) * nb] @ b[bj * nb:(bj + 1) * nb].T
 
+    def gemm_nt_stair_merged(self, c, a, b, P, p, Q, q, bi0, bj0, nb, first_cols):
+        self.gemm_nt_stair(c, a, b, P, p, Q, q, bi0, bj0, nb)      # program order: the first columns are done when this returns
+        self.merged_launches = getattr(self, 'merged_launches', 0) + 1
+        return first_cols
+
+    def count_reset(self):
+        pass
+
+    def wait_count(self, owner, target):
+        pass
+
+    def overlaps(self, other):
+        return True
+
     def gemm_nn(self, c, a, b):
         c -= a @ b
 
@@ -148,6 +166,19 @@ class NumpyTileBackend(object):
 
     def prior_diag(self, xs, terms):
         return oracle.paired_cov(_terms(terms), xs, xs)
+
+
+class _SideView(object):
+    """the look-ahead 'context' of the numpy backend: the same arrays, the same status words, another identity"""
+
+    def __init__(self, main):
+        object.__setattr__(self, '_main', main)
+
+    def __getattr__(self, name):
+        return getattr(object.__getattribute__(self, '_main'), name)
+
+    def __setattr__(self, name, value):
+        setattr(object.__getattribute__(self, '_main'), name, value)
 
 
 class GlooGroup(object):

@@ -46,8 +46,11 @@ def _worker(rank, world, P, Q, n, d, m, nb, port, seed, lookahead='1', super_min
         gp = DistributedGP(grid, NumpyTileBackend(), x, kernel, kernel + nugget, nb=nb, super_min_rows=super_min_rows)
         if super_min_rows == 0:
             assert max(len(b) for b in gp.super_panels()) == 2 and gp.super_panels()[0] == [0]
+            os.environ['MGPI_DIST_MERGED_MIN'] = '0'       # the merged form of the trailing update wherever it can apply
         gp.build()
         logdet = gp.factor()
+        if super_min_rows == 0 and lookahead == '1' and n >= 100:
+            assert getattr(gp.be, 'merged_launches', 0) > 0, 'the merged trailing update was never taken' 
         alpha = gp.solve(f)
         mean = gp.mean(xs)
         var = gp.variance(xs)
