@@ -107,15 +107,17 @@ def test_hip_tile_backend_multi_rank_on_one_gpu(P, Q, n, m, nb, d, lookahead):
     """P*Q ranks share GPU 0 (gloo, host-staged collectives - tests/dist_gpu_worker.py): the multi-rank tile
     distribution with the HIP kernels, which a one-GPU box cannot otherwise run.  At most 4 ranks + this process
     touch the card (the box allows 6).  Once with single block columns per trailing update, once with super-panels of two
-    (MGPI_DIST_SUPER_MIN=0: contraction 2 nb, slabs side by side) - the schedule the large runs use."""
+    (MGPI_DIST_SUPER_MIN=0: contraction 2 nb, slabs side by side) and the merged staircase update wherever it can apply
+    (MGPI_DIST_MERGED_MIN=0: the next super-panel's block columns first, counted; the look-ahead context starts on the count) -
+    the schedule the large runs use."""
     _run_ranks(P * Q, ('staged', P, Q, n, m, nb, d, lookahead))
-    _run_ranks(P * Q, ('staged', P, Q, n, m, nb, d, lookahead), extra_env={'MGPI_DIST_SUPER_MIN': '0'})
+    _run_ranks(P * Q, ('staged', P, Q, n, m, nb, d, lookahead), extra_env={'MGPI_DIST_SUPER_MIN': '0', 'MGPI_DIST_MERGED_MIN': '0'})
 
 
 def test_staged_2x2_at_c2_size():
     """the 2 x 2 grid at N = 8192 (BASELINE.json configs[1]'s size), nb = 512, look-ahead, super-panels: four ranks on GPU 0
     with host-staged collectives, every rank against the oracle [r3: the staged tests stopped at N = 2300]"""
-    _run_ranks(4, ('staged', 2, 2, 8192, 256, 512, 3, 1), timeout=900, extra_env={'MGPI_DIST_SUPER_MIN': '2048'})
+    _run_ranks(4, ('staged', 2, 2, 8192, 256, 512, 3, 1), timeout=900, extra_env={'MGPI_DIST_SUPER_MIN': '2048', 'MGPI_DIST_MERGED_MIN': '1024'})
 
 
 def _single_rank_gp(x, ell, nb=512, **kw):

@@ -257,3 +257,16 @@ def test_rccl_load_failure_is_reported_not_fatal(tmp_path):
     out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, MGPI_RCCL_LIB=str(tmp_path / 'no_such_librccl.so')),
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and 'COMM-ERR-OK' in out.stdout, out.stdout[-1000:] + out.stderr[-2000:]
+
+
+def test_riders_rule(monkeypatch):
+    """where condition_diag lets the queries ride through the factorisation (gp.py::riders_pay): the chain-bound regime only"""
+    from mgpi_amd.gp import riders_pay
+    monkeypatch.delenv('MGPI_RIDERS', raising=False)
+    monkeypatch.delenv('MGPI_RIDERS_MAX_N', raising=False)
+    assert riders_pay(8192, 4096) and riders_pay(16384, 128) and riders_pay(300, 300)
+    assert not riders_pay(32768, 4096) and not riders_pay(8192, 127) and not riders_pay(1000, 1001)
+    monkeypatch.setenv('MGPI_RIDERS', '0')
+    assert not riders_pay(8192, 4096)
+    monkeypatch.setenv('MGPI_RIDERS', '1')
+    assert riders_pay(32768, 4096) and not riders_pay(100, 1000)
