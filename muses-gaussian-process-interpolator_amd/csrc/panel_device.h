@@ -35,14 +35,6 @@ __device__ __forceinline__ double rsq_refined(double d) {
     return y;
 }
 
-// 1/d to the last bit or one short of it: hardware estimate (~2^-27) + two Newton steps in fma form (a division is a
-// ~15-instruction dependent chain; the single-rhs sweeps take 16 reciprocals per wave and sub-block)
-__device__ __forceinline__ double rcp_newton2(double d) {
-    double p = __builtin_amdgcn_rcp(d);
-    p = fma(p, fma(-d, p, 1.0), p);
-    return fma(p, fma(-d, p, 1.0), p);
-}
-
 // ---- 64-wide triangular block solves ---------------------------------------------------------------------
 // Right-looking (column-sweep) substitution: once x_k is final every later unknown subtracts its coefficient
 // times x_k, so the updates of a step are independent FMAs; the division is a multiply by a reciprocal kept on
