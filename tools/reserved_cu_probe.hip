@@ -71,3 +71,33 @@ extern "C" int probe_load_wait(unsigned* exited, unsigned* stayed) {
     *stayed = h[1];
     return 0;
 }
+
+// a chain of n dependent trivial launches (one workgroup of 64 threads each) on a stream of its own: milliseconds for all of them.
+// Beside the load this isolates what a dependent launch costs when another grid is resident - no arithmetic, no LDS to speak of.
+__global__ void tiny_kernel(unsigned* p) { if (threadIdx.x == 0) p[2] += 1u; }
+__global__ void chain_fma_kernel(int n, const double* in, double* out) {        // one wave, n dependent fp64 fmas: the clock it runs at
+    double a = in[threadIdx.x] * 1e-3, b = 1.0000001;
+    for (int i = 0; i < n; ++i) a = fma(a, b, 1e-9);
+    if (a == 1.2345) out[0] = a;
+}
+static hipStream_t g_chain = nullptr;
+static hipEvent_t g_e0, g_e1;
+extern "C" double probe_tiny_chain(int n, int fma_len) {
+    if (!g_chain) {
+        int lo, hi;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&g_chain, hipStreamNonBlocking, hi) != hipSuccess) return -1.0;
+        hipEventCreate(&g_e0);
+        hipEventCreate(&g_e1);
+    }
+    hipEventRecord(g_e0, g_chain);
+    for (int i = 0; i < n; ++i) {
+        if (fma_len > 0) hipLaunchKernelGGL(chain_fma_kernel, dim3(1), dim3(64), 0, g_chain, fma_len, g_in, g_out);
+        else hipLaunchKernelGGL(tiny_kernel, dim3(1), dim3(64), 0, g_chain, g_stats);
+    }
+    hipEventRecord(g_e1, g_chain);
+    if (hipEventSynchronize(g_e1) != hipSuccess) return -2.0;
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, g_e0, g_e1);
+    return (double)ms;
+}

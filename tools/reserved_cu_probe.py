@@ -48,3 +48,22 @@ for n in (1024, 2048, 4096):
         line += ' | %d CUs per SE reserved (%d workgroups left, %d stayed): %s ms%s' % (
             reserve, ex.value, st.value, ' '.join('%.3f' % v for v in got[1:]) or '-', '' if still else ' [load ended early]')
     print(line, flush=True)
+
+# what a dependent launch costs, and what clock a dependent fp64 chain sees, alone and beside the load (2 CUs per SE left empty)
+probe.probe_tiny_chain.restype = ctypes.c_double
+probe.probe_load_start(1, 0, 1)          # creates the probe's buffers
+ex, st = ctypes.c_uint(0), ctypes.c_uint(0)
+probe.probe_load_wait(ctypes.byref(ex), ctypes.byref(st))
+for label, reserve in (('alone', None), ('beside the load, 2 CUs per SE empty', 2), ('beside the load, 4 CUs per SE empty', 4)):
+    if reserve is not None:
+        assert probe.probe_load_start(3000000, reserve, 512) == 0
+        probe.probe_tiny_chain(50, 0)
+    tiny = min(probe.probe_tiny_chain(400, 0) for _ in range(3)) / 400 * 1e3
+    fma = min(probe.probe_tiny_chain(50, 20000) for _ in range(3)) / 50 * 1e3
+    if reserve is not None:
+        running = probe.probe_load_running()
+        probe.probe_load_wait(ctypes.byref(ex), ctypes.byref(st))
+    else:
+        running = 1
+    print('%s: %.2f us per trivial dependent launch; %.2f us per launch of 20000 dependent fp64 fmas (%.1f ns per fma)%s'
+          % (label, tiny, fma, fma / 20000 * 1e3, '' if running else ' [load ended early]'), flush=True)
