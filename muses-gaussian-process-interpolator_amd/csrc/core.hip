@@ -62,6 +62,7 @@ extern "C" int mgpi_ctx_create(int device_id, int nb, mgpi_ctx** out) {
     MGPI_HIP_TRY(hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming));
     MGPI_HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     c->streams_overlap = -1;
+    c->skinny_tiles = 448;
     c->no_lookahead = getenv("MGPI_NO_LOOKAHEAD") && atoi(getenv("MGPI_NO_LOOKAHEAD")) != 0;
     c->pivot_tol = getenv("MGPI_PIVOT_TOL") ? atof(getenv("MGPI_PIVOT_TOL")) : 100.0 * 2.220446049250313e-16;
     MGPI_HIP_TRY(hipEventCreate(&c->ev0));

@@ -488,7 +488,11 @@ static int launch_shape(mgpi_ctx* ctx, int lower_only, int64_t m, int64_t n, int
     // Skinny updates (the next panel's block column: t x 512 with t <= 8192) give fewer 128 x 128 tiles than the chip has
     // workgroup slots (256 CUs x 2): half the CUs idle for the length of one K = 512 tile, on the chain the next panel waits
     // for.  Narrower tiles fill the chip (N = 8192: 240 tiles -> 480; measured 184 -> ... us per column update).
-    static const int64_t skinny = getenv("MGPI_GEMM_SKINNY_TILES") ? atoll(getenv("MGPI_GEMM_SKINNY_TILES")) : 448;
+    // [r3] the threshold follows the size of the factorisation the context last enqueued (chol.hip, potrf_enqueue): 448 beside
+    // a large trailing update, which fills the idle slots anyway; 1300 up to N = 16384, where one to two and a half rounds of
+    // 128 x 128 tiles leave a ragged last round on the chain (C2: 13.03 -> 12.59 ms per step, C3/C4 +0.1..0.3 % if applied there).
+    static const int64_t skinny_env = getenv("MGPI_GEMM_SKINNY_TILES") ? atoll(getenv("MGPI_GEMM_SKINNY_TILES")) : -1;
+    const int64_t skinny = skinny_env >= 0 ? skinny_env : ctx->skinny_tiles;
     if (m % 128 == 0 && n % 128 == 0 && (m / 128) * (n / 128) < skinny) {
         if ((m / 128) * (n / 64) < skinny) return launch_one<64, 64, AK, BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);
         return launch_one<128, 64, AK, BKM, false>(ctx, m, n, k, A, lda, B, ldb, C, ldc);

@@ -51,6 +51,7 @@ struct mgpi_ctx {
     size_t work_bytes;
     mgpi_pool* pool;              // freed matrix buffers awaiting reuse (core.hip)
     int streams_overlap;          // -1 not asked yet; 1 / 0: kernels of stream and stream2 do / do not run side by side (chol.hip)
+    int64_t skinny_tiles;         // plain gemms with fewer 128 x 128 tiles than this take narrower tiles (gemm.hip; set per factorisation)
     double pivot_tol;             // a pivot must exceed pivot_tol * K_kk(original); 0 = LAPACK's "pivot > 0" rule
 };
 
