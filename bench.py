@@ -325,7 +325,7 @@ class DistributedStep(object):
         gp = self.gp
         if os.environ.get('MGPI_BENCH_PHASES') == '1':      # developer switch: a host sync and a wall-clock stamp per phase (stderr)
             t, out = time.perf_counter(), []
-            for name, fn in (('build', gp.build), ('factor', gp.factor), ('solve', lambda: gp.solve(self.f)),
+            for name, fn in (('build', gp.build), ('factor', lambda: gp.factor(source_f=self.f)), ('solve', lambda: gp.solve(self.f)),
                              ('mean', lambda: setattr(self, 'mean', gp.mean(self.xs))),
                              ('variance', lambda: setattr(self, 'var', gp.variance(self.xs)))):
                 fn()
@@ -336,8 +336,8 @@ class DistributedStep(object):
             sys.stderr.write('phases: ' + ', '.join(out) + '\n')
             return
         gp.build()
-        gp.factor()
-        gp.solve(self.f)
+        gp.factor(source_f=self.f)                  # the forward substitution rides along, block step by block step
+        gp.solve(self.f)                            # ... so this is the backward sweep
         self.mean = gp.mean(self.xs)
         self.var = gp.variance(self.xs)
 

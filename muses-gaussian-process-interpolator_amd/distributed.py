@@ -279,6 +279,16 @@ class HipTileBackend(object):
         _lib.check(self.lib.mgpi_cov_block_dev(self.ctx.handle, XR.handle, n_rows_valid, XC.handle, n_cols_valid, desc, count,
                                                out.handle))
 
+    def points(self, x):
+        """a (rows x D) coordinate array on the device, windowed by rows afterwards"""
+        return _lib.DeviceMatrix.from_host(self.ctx, x)
+
+    def cov_dev(self, XR, n_rows_valid, XC, n_cols_valid, terms, out):
+        """`cov` with the coordinates already on the device (windows of `points`)"""
+        desc, count = _lib.make_terms(terms)
+        _lib.check(self.lib.mgpi_cov_block_dev(self.ctx.handle, XR.handle, int(n_rows_valid), XC.handle, int(n_cols_valid), desc,
+                                               count, out.handle))
+
     def status_reset(self):
         _lib.check(self.lib.mgpi_ctx_status_reset(self.ctx.handle))
 
@@ -412,6 +422,7 @@ class DistributedGP(object):
         self.alpha = None
         self.trailing_flops = 0.0   # algorithmic flops of this rank's trailing updates on the main stream (bench.py roofline)
         self.column_flops = 0.0     # ... and of its next-panel column updates on the look-ahead stream
+        self._fwd_y = self._fwd_acc = self._fwd_f = None   # forward substitution riding along with factor(source_f=...)
         self.row_panels = None        # L[I][k] for the local block rows, every block step k (filled by factor), as super-panel slabs
         self._row_panel_view = None   # k -> (first row, first column) of L[I > k][k] inside row_panels
         self._dinv = None             # {k: -(L_kk)^-1} for the diagonal blocks this rank owns (variance sweep only)
@@ -448,8 +459,17 @@ class DistributedGP(object):
         xr[:nvr] = self.x[gi[:nvr]]
         xc[:nvc] = self.x[gj[:nvc]]
         if self.A is None:
-            self.A = be.alloc(self.mloc, self.nloc)        # every entry is (re)written by the tile build below
-        be.cov(xr, xc, self.solve_terms, self.A, nvr, nvc)
+            self.A = be.alloc(self.mloc, self.nloc)        # zero; the blocks above the global diagonal stay so and are never read
+        # one launch per local block column, over the local block rows I >= J only (the factorisation never reads the rest:
+        # half the kernel evaluations of the full local rectangle)
+        XR, XC = be.points(xr), be.points(xc)
+        for lj, J in enumerate(self.col_blocks):
+            il = self._first_local(self.row_blocks, J - 1)
+            rows = self.mloc - il * nb
+            if rows <= 0:
+                continue
+            be.cov_dev(be.window(XR, il * nb, rows), min(max(nvr - il * nb, 0), rows), be.window(XC, lj * nb, nb),
+                       min(max(nvc - lj * nb, 0), nb), self.solve_terms, be.window(self.A, il * nb, rows, lj * nb, nb))
         # padded global indices (>= n) get a unit diagonal so the padded matrix stays positive definite
         for li, I in enumerate(self.row_blocks):
             if (I + 1) * nb > self.n and I % self.g.Q == self.g.q:
@@ -598,8 +618,37 @@ class DistributedGP(object):
             self.column_flops += flops                           # next-panel column updates on the look-ahead stream
         return live
 
-    def factor(self, lookahead=None):
-        """2-D block-cyclic right-looking Cholesky in super-panels.  With look-ahead (default; MGPI_DIST_LOOKAHEAD=0 turns it
+    def _forward_blocks(self, blocks, be):
+        """the forward substitution L y = f for the block steps `blocks`, right-looking: each needs only its own, finished
+        block column - run right behind that column's panel, on the stream the panels run on, beside the trailing update
+        (the single-GPU path does the same on its third stream, csrc/chol.hip mgpi_posv_dev).  `_acc` (local ROW order)
+        collects  - sum_{J < I, J local} L[I][J] y_J  for every local block row I."""
+        if self._fwd_y is None:
+            return
+        g, nb, A, W = self.g, self.nb, self.A, be.window
+        y, acc = self._fwd_y, self._fwd_acc
+        for k in blocks:
+            pk, qk = k % g.P, k % g.Q
+            kr, kc = k // g.P, k // g.Q
+            yk = W(y, k * nb, nb)
+            if g.p == pk:
+                s = W(acc, kr * nb, nb)
+                g.reduce_row(be, s, qk)
+                if g.q == qk:
+                    be.axpy(1.0, s, yk)
+                    be.trsv(W(A, kr * nb, nb, kc * nb, nb), yk, 0)
+            if g.q == qk:                                       # y_k multiplies the blocks L[I][k]: process column qk
+                g.bcast_col(be, yk, pk)
+                i0 = self._first_local(self.row_blocks, k)      # local row blocks [i0:) have I > k
+                if i0 < len(self.row_blocks):
+                    mt = self.mloc - i0 * nb
+                    be.gemv(W(A, i0 * nb, mt, kc * nb, nb), yk, W(acc, i0 * nb, mt), 0)       # acc_I -= L[I][k] y_k
+
+    def factor(self, lookahead=None, source_f=None):
+        """2-D block-cyclic right-looking Cholesky in super-panels.
+        source_f: a right-hand side whose forward substitution runs along with the factorisation, block step by block step
+        (`solve(source_f)` afterwards is then the backward sweep alone).
+  With look-ahead (default; MGPI_DIST_LOOKAHEAD=0 turns it
         off) the update of the block columns of super-panel s+1 and then that super-panel's work - diagonal factorisations,
         panel solves and all their broadcasts - run on a second stream while the rest of the trailing update of super-panel s
         runs on the main stream, so the xGMI transfers and the latency-bound panels hide behind the MFMA work.  Every rank
@@ -630,6 +679,14 @@ class DistributedGP(object):
         self._slab_offset, self._row_panel_view = offs, views
         if self.row_panels is None or self.row_panels.rows != total or self.row_panels.cols != wmax:
             self.row_panels = be.alloc(total, wmax, zero=False)
+        self._fwd_y = self._fwd_acc = self._fwd_f = None
+        if source_f is not None and os.environ.get('MGPI_DIST_FORWARD', '1') != '0':
+            f = np.zeros(self.np_)
+            f[:self.n] = _lib.as_f64(source_f).reshape(-1)
+            self._fwd_y = be.alloc(self.np_, 1)                 # replicated right-hand side; block k becomes y_k where it is solved
+            be.upload(self._fwd_y, f)
+            self._fwd_acc = be.alloc(max(self.mloc, nb), 1)
+            self._fwd_f = f
         side.status_reset()
         side.wait(be)                                           # the build (and the allocations' fills) precede the first panel
         # Merged trailing update, as on one GPU (csrc/chol.hip): while at least merged_min_rows local rows trail, ONE launch
@@ -646,6 +703,7 @@ class DistributedGP(object):
         ncols = len(self.col_blocks)
         pan = self._panel_super(0, side, bufs[0])
         be.wait(side)
+        self._forward_blocks(supers[0], side)                   # behind the point the main stream waits for
         for s in range(len(supers)):
             nxt = s + 1 < len(supers)
             j0 = pan['j0']
@@ -653,6 +711,7 @@ class DistributedGP(object):
                 self._update(pan, j0, ncols, be)
                 if nxt:
                     pan = self._panel_super(s + 1, be, bufs[(s + 1) % 2])
+                    self._forward_blocks(supers[s + 1], be)
                 continue
             # (a) main stream: the rest of the trailing update of super-panel s.  (b) side stream (high priority): the block
             # columns of the next super-panel, then that super-panel - its diagonal factorisations, panel solves and all of
@@ -669,7 +728,10 @@ class DistributedGP(object):
                     self._update(pan, j0, j0 + nown, side)
             nxt_pan = self._panel_super(s + 1, side, bufs[(s + 1) % 2])
             be.wait(side)
+            self._forward_blocks(supers[s + 1], side)           # the trailing update does not wait for these
             pan = nxt_pan
+        if side is not be:
+            be.wait(side)                                       # the last forward steps
         # logdet and the first failing pivot, agreed by everyone (one read-back for the whole factorisation)
         info_first, logdiag = side.status_read()
         if g.world > 1 or g.always:
@@ -683,6 +745,7 @@ class DistributedGP(object):
             worst = float(be.download(m).reshape(-1)[0])
             info_first = int(-worst) if worst > -1e299 else 0
         if info_first:
+            self._fwd_y = self._fwd_acc = self._fwd_f = None
             raise _lib.NotPositiveDefinite(info_first, 'covariance is not positive definite! (pivot %d)' % info_first)
         self.logdet = 2.0 * logdiag
         return self.logdet
@@ -701,11 +764,16 @@ class DistributedGP(object):
         A, W = self.A, be.window
         f = np.zeros(self.np_)
         f[:self.n] = _lib.as_f64(source_f).reshape(-1)
-        y = be.alloc(self.np_, 1)                               # replicated right-hand side; block k becomes the solution on
-        be.upload(y, f)                                         # the ranks that need it
+        rode = getattr(self, '_fwd_f', None) is not None and np.array_equal(f, self._fwd_f)
+        if rode:
+            y = self._fwd_y                                     # factor(source_f=...) left y here, block k on its diagonal owner
+            self._fwd_y = self._fwd_acc = self._fwd_f = None    # the backward sweep overwrites it
+        else:
+            y = be.alloc(self.np_, 1)                           # replicated right-hand side; block k becomes the solution on
+            be.upload(y, f)                                     # the ranks that need it
         # forward: L y = f.  acc (local ROW order) collects  - sum_{J < I, J local} L[I][J] y_J  for every local block row I
         acc = be.alloc(max(self.mloc, nb), 1)
-        for k in range(self.nblk):
+        for k in (() if rode else range(self.nblk)):
             pk, qk = k % g.P, k % g.Q
             kr, kc = k // g.P, k // g.Q
             yk = W(y, k * nb, nb)

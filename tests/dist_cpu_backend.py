@@ -77,6 +77,12 @@ class NumpyTileBackend(object):
         if n_rows_valid and n_cols_valid:
             out[:n_rows_valid, :n_cols_valid] = oracle.x2cov_chunked(_terms(terms), x_rows[:n_rows_valid], x_cols[:n_cols_valid])
 
+    def points(self, x):
+        return np.array(x, dtype=float)
+
+    def cov_dev(self, x_rows, n_rows_valid, x_cols, n_cols_valid, terms, out):
+        self.cov(x_rows, x_cols, terms, out, n_rows_valid, n_cols_valid)
+
     def status_reset(self):
         self._pivot, self._logdiag = 0, 0.0
 

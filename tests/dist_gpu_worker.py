@@ -92,8 +92,10 @@ def main():
     nug = mgpi.WhiteNoiseKernel(1e-2)
     gp = DistributedGP(grid, be, x, k.terms(), (k + nug).terms(), nb=nb)
     gp.build()
-    logdet = gp.factor(lookahead=bool(lookahead))
+    logdet = gp.factor(lookahead=bool(lookahead), source_f=f)     # forward substitution beside the block steps
     alpha = gp.solve(f)
+    both = gp.solve(f)                                            # both sweeps after the fact
+    assert np.max(np.abs(both - alpha)) <= 1e-11 * np.max(np.abs(alpha)), np.max(np.abs(both - alpha))
     mean = gp.mean(xs)
     var = gp.variance(xs)
 

@@ -48,10 +48,16 @@ def _worker(rank, world, P, Q, n, d, m, nb, port, seed, lookahead='1', super_min
             assert max(len(b) for b in gp.super_panels()) == 2 and gp.super_panels()[0] == [0]
             os.environ['MGPI_DIST_MERGED_MIN'] = '0'       # the merged form of the trailing update wherever it can apply
         gp.build()
-        logdet = gp.factor()
+        logdet = gp.factor(source_f=f)                     # the forward substitution rides along with the block steps
         if super_min_rows == 0 and lookahead == '1' and n >= 100:
             assert getattr(gp.be, 'merged_launches', 0) > 0, 'the merged trailing update was never taken' 
-        alpha = gp.solve(f)
+        assert gp._fwd_f is not None
+        alpha = gp.solve(f)                                # the backward sweep alone
+        assert gp._fwd_f is None
+        other = gp.solve(2.0 * f)                          # another right-hand side: both sweeps, after the fact
+        assert np.max(np.abs(other - 2.0 * alpha)) <= 1e-12 * np.max(np.abs(alpha))
+        both = gp.solve(f)
+        assert np.max(np.abs(both - alpha)) <= 1e-12 * np.max(np.abs(alpha))
         mean = gp.mean(xs)
         var = gp.variance(xs)
 

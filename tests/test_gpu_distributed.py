@@ -39,8 +39,9 @@ def test_hip_tile_backend_single_rank(n, m, nb, lookahead):
     ctx = mgpi.Context(device=0, nb=nb)
     gp = DistributedGP(ProcessGrid(LocalTransport(), 1, 1), HipTileBackend(ctx), x, k.terms(), (k + nug).terms(), nb=nb)
     gp.build()
-    logdet = gp.factor(lookahead=lookahead)
+    logdet = gp.factor(lookahead=lookahead, source_f=f)
     alpha = gp.solve(f)
+    assert relmax(gp.solve(f), alpha) < 1e-11               # both sweeps after the fact
     mean = gp.mean(xs)
     var = gp.variance(xs)
 
@@ -138,7 +139,7 @@ def test_single_rank_driver_at_c3_against_the_single_gpu_path():
     xq = xs[:1024]
     gp, k, nug = _single_rank_gp(x, ell)
     gp.build()
-    logdet = gp.factor()
+    logdet = gp.factor(source_f=f)                           # as bench.py runs it: the forward sweep beside the factorisation
     alpha = gp.solve(f)
     mean = gp.mean(xq)
     var = gp.variance(xq, m_slab=512)                        # two slabs
