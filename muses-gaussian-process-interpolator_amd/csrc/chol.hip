@@ -284,6 +284,36 @@ static int invert_lower_blocks(mgpi_ctx* ctx, const double* L, int64_t lda, int6
     return 0;
 }
 
+// [r3] The same inverses by recursive halving, for `count` blocks of width nb = 64 * 2^p stored nb (nb + 1) doubles apart
+// (mgpi_dinv_block): with L = [A 0; C B] the inverse is [A^-1 0; -B^-1 C A^-1  B^-1], so after the 64 x 64 diagonal tiles are
+// inverted (ONE batched substitution launch over all tiles of all blocks) every level h = 64, 128, .. is two batched gemms
+// over all (block, pair) sub-problems - the skewed block stride makes their offsets one arithmetic progression, 2h (ld + 1)
+// in L and in X alike.  In the stored sign (X = -L^-1, "C -= A B" gemms on zeroed targets):  T = -C X11,  X21 = -X22 T.
+// 1 + 2 log2(nb / 64) kernel launches (7 at nb = 512) instead of 2 nb / 64 - 1 (15), none of them a 64-row substitution over
+// the whole block width: 0.3 -> 0.1 ms, which matters since the single-right-hand-side backward sweep uses the inverses too.
+static int invert_lower_blocks_halving(mgpi_ctx* ctx, const double* L, int64_t lda, double* X, int64_t nb, int64_t count,
+                                       double* T) {
+    if (count <= 0) return 0;
+    const int64_t sX = nb * (nb + 1);
+    hipLaunchKernelGGL(neg_identity_kernel, dim3((unsigned)((count * nb + 255) / 256)), dim3(256), 0, ctx->stream, X, nb, sX, nb, (int)count);
+    const int64_t tiles = count * (nb / IB);
+    MGPI_REQUIRE(tiles < 65536, "block inversion: %lld diagonal tiles", (long long)tiles);
+    hipLaunchKernelGGL(trsm_cols_kernel<false>, dim3(1, (unsigned)tiles), dim3(256), 0, ctx->stream, L, lda, X, nb, IB * (lda + 1),
+                       IB * (nb + 1));
+    for (int64_t h = IB; 2 * h <= nb; h *= 2) {
+        const int subs = (int)(count * (nb / (2 * h)));
+        MGPI_HIP_TRY(hipMemsetAsync(T, 0, (size_t)subs * h * h * sizeof(double), ctx->stream));
+        MGPI_TRY(mgpi_launch_gemm_nn_batched(ctx, h, h, h, L + h * lda, lda, 2 * h * (lda + 1), X, nb, 2 * h * (nb + 1), T, h, h * h, subs));
+        MGPI_TRY(mgpi_launch_gemm_nn_batched(ctx, h, h, h, X + h * (nb + 1), nb, 2 * h * (nb + 1), T, h, h * h, X + h * nb, nb,
+                                             2 * h * (nb + 1), subs));
+    }
+    MGPI_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// block b of the cache: nb x nb, row stride nb, nb (nb + 1) doubles apart (see invert_lower_blocks_halving)
+static inline double* mgpi_dinv_block(const mgpi_mat* Lm, int64_t b) { return Lm->dinv + b * Lm->dinv_nb * (Lm->dinv_nb + 1); }
+
 static int ensure_dinv(mgpi_ctx* ctx, const mgpi_mat* Lc) {
     mgpi_mat* Lm = const_cast<mgpi_mat*>(Lc);          // a cache on the factor, invisible to the caller
     const int64_t nb = ctx->nb;
@@ -293,14 +323,26 @@ static int ensure_dinv(mgpi_ctx* ctx, const mgpi_mat* Lc) {
         mgpi_pool_free(ctx, Lm->dinv, Lm->dinv_bytes);
         Lm->dinv = nullptr;
     }
-    const size_t bytes = (size_t)pn * (size_t)nb * sizeof(double);
+    const int64_t nfull = pn / nb, wlast = pn - nfull * nb;          // full blocks, width of a narrower last one
+    const int64_t sX = nb * (nb + 1);
+    const size_t bytes = (size_t)(nfull + 1) * (size_t)sX * sizeof(double);
     MGPI_TRY(mgpi_pool_alloc(ctx, bytes, &Lm->dinv, &Lm->dinv_bytes));
     double* X = Lm->dinv;
     const int64_t lda = Lm->ld;
     MGPI_HIP_TRY(hipMemsetAsync(X, 0, bytes, ctx->stream));
-    const int64_t nfull = pn / nb, wlast = pn - nfull * nb;          // full blocks, width of a narrower last one
-    MGPI_TRY(invert_lower_blocks(ctx, Lm->d, lda, nb * (lda + 1), X, nb, nb * nb, nb, (int)nfull));
-    MGPI_TRY(invert_lower_blocks(ctx, Lm->d + nfull * nb * (lda + 1), lda, 0, X + nfull * nb * nb, nb, 0, wlast, wlast > 0 ? 1 : 0));
+    static const int halving_env = getenv("MGPI_DINV_HALVING") ? atoi(getenv("MGPI_DINV_HALVING")) : 1;
+    const bool pow2 = nb >= IB && ((nb / IB) & (nb / IB - 1)) == 0;
+    if (halving_env != 0 && pow2 && nfull * (nb / IB) < 65536) {
+        double* T = nullptr;
+        size_t tbytes = 0;
+        MGPI_TRY(mgpi_pool_alloc(ctx, (size_t)nfull * (size_t)(nb / 2) * (size_t)(nb / 2) * sizeof(double) + 64, &T, &tbytes));
+        const int rc = invert_lower_blocks_halving(ctx, Lm->d, lda, X, nb, nfull, T);
+        mgpi_pool_free(ctx, T, tbytes);                              // reuse is ordered on this stream
+        if (rc) return rc;
+    } else {
+        MGPI_TRY(invert_lower_blocks(ctx, Lm->d, lda, nb * (lda + 1), X, nb, sX, nb, (int)nfull));
+    }
+    MGPI_TRY(invert_lower_blocks(ctx, Lm->d + nfull * nb * (lda + 1), lda, 0, X + nfull * sX, nb, 0, wlast, wlast > 0 ? 1 : 0));
     Lm->dinv_nb = nb;
     return 0;
 }
@@ -345,18 +387,36 @@ __global__ void save_diag_kernel(const double* __restrict__ A, int64_t lda, int6
 
 // out[0] = sum_i log(A[i][i]) over i < n (single workgroup, fixed summation order => deterministic)
 // accumulate != 0: out[0] += sum (the block-by-block factorisation of the multi-GPU driver)
+// range != nullptr: range[0] = min_i A[i][i], range[1] = max_i A[i][i] (what trsv_sweeps judges the factor's conditioning by)
 __global__ __launch_bounds__(256) void logdiag_kernel(const double* __restrict__ A, int64_t lda, int64_t n,
-                                                      double* __restrict__ out, int accumulate) {
-    __shared__ double part[256];
-    double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) s += log(A[i * lda + i]);
+                                                      double* __restrict__ out, int accumulate, double* __restrict__ range) {
+    __shared__ double part[256], lo[256], hi[256];
+    double s = 0.0, mn = INFINITY, mx = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const double d = A[i * lda + i];
+        s += log(d);
+        mn = fmin(mn, d);                                     // a NaN diagonal (failed factorisation) is ignored here: the status says so
+        mx = fmax(mx, d);
+    }
     part[threadIdx.x] = s;
+    lo[threadIdx.x] = mn;
+    hi[threadIdx.x] = mx;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        if ((int)threadIdx.x < w) {
+            part[threadIdx.x] += part[threadIdx.x + w];
+            lo[threadIdx.x] = fmin(lo[threadIdx.x], lo[threadIdx.x + w]);
+            hi[threadIdx.x] = fmax(hi[threadIdx.x], hi[threadIdx.x + w]);
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + part[0] : part[0];
+    if (threadIdx.x == 0) {
+        out[0] = accumulate ? out[0] + part[0] : part[0];
+        if (range != nullptr) {
+            range[0] = lo[0];
+            range[1] = hi[0];
+        }
+    }
 }
 
 // One wave that returns once *counter has reached `want` (wrap-safe): how the look-ahead stream waits for PART of a kernel
@@ -502,6 +562,7 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
                      (long long)K->prows, (long long)K->pcols, IB);
     }
     MGPI_HIP_TRY(hipSetDevice(ctx->device));
+    K->diag_min = K->diag_max = 0.0;                 // unknown until this factorisation's status is read
     if (K->dinv) {                                   // inverse diagonal blocks of a previous factor
         mgpi_pool_free(ctx, K->dinv, K->dinv_bytes);
         K->dinv = nullptr;
@@ -792,7 +853,7 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     mgpi_prof_end(ctx, 2);
 
     hipLaunchKernelGGL(logdiag_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, ndiag, ctx->d_scal + (keep_status ? 1 : 0),
-                       keep_status);
+                       keep_status, keep_status ? (double*)nullptr : ctx->d_scal + 4);
     MGPI_HIP_TRY(hipGetLastError());
     K->factored = tall ? 0 : 1;          // mgpi_potrf_dev takes it back when the status says otherwise
     join_on_error.armed = false;
@@ -802,19 +863,22 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
 // the status of the factorisation just enqueued: one read-back of the failing-pivot word and sum log L_ii
 static int potrf_status(mgpi_ctx* ctx, mgpi_mat* K, double* logdet) {
     int info = 0;
-    double ld = 0.0;
+    double sc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};          // [0] sum log L_ii, [4] min L_ii, [5] max L_ii
     if (ctx->h_pinned) {
         char* land = (char*)ctx->h_pinned;
         MGPI_HIP_TRY(hipMemcpyAsync(land, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        MGPI_HIP_TRY(hipMemcpyAsync(land + 8, ctx->d_scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        MGPI_HIP_TRY(hipMemcpyAsync(land + 8, ctx->d_scal, sizeof(sc), hipMemcpyDeviceToHost, ctx->stream));
         MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
         memcpy(&info, land, sizeof(int));
-        memcpy(&ld, land + 8, sizeof(double));
+        memcpy(sc, land + 8, sizeof(sc));
     } else {
         MGPI_HIP_TRY(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        MGPI_HIP_TRY(hipMemcpyAsync(&ld, ctx->d_scal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        MGPI_HIP_TRY(hipMemcpyAsync(sc, ctx->d_scal, sizeof(sc), hipMemcpyDeviceToHost, ctx->stream));
         MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
+    const double ld = sc[0];
+    K->diag_min = (sc[4] > 0.0 && sc[4] <= sc[5] && sc[5] < INFINITY) ? sc[4] : 0.0;
+    K->diag_max = K->diag_min > 0.0 ? sc[5] : 0.0;
     if (info < 0) {
         K->factored = 0;
         mgpi_set_error("mgpi_potrf_dev: the trailing update's progress counter was not reached (internal error)");
@@ -885,6 +949,7 @@ extern "C" int mgpi_posv_riders_dev(mgpi_ctx* ctx, mgpi_mat* KR, mgpi_mat* B, do
     mgpi_prof_begin(ctx, 6);
     const int rc = trsv_sweeps(ctx, &L, rhs, 2);
     mgpi_prof_end(ctx, 6);
+    if (L.dinv) mgpi_pool_free(ctx, L.dinv, L.dinv_bytes);       // the inverted diagonal blocks the sweep built on the temporary handle
     return rc;
 }
 
@@ -1171,7 +1236,7 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
                 ctx->lean = 0;
                 ctx->gemm_zero_c = 1;
                 double* dst = Xout ? Xout + r0 * ldb : T;
-                int rc = mgpi_launch_gemm(ctx, 0, 1, 0, w, nc, w, Lm->dinv + r0 * nb, nb, B + r0 * ldb, ldb, dst, Xout ? ldb : nc);
+                int rc = mgpi_launch_gemm(ctx, 0, 1, 0, w, nc, w, mgpi_dinv_block(Lm, r0 / nb), nb, B + r0 * ldb, ldb, dst, Xout ? ldb : nc);
                 ctx->gemm_zero_c = 0;
                 ctx->lean = lean;
                 if (rc) return rc;
@@ -1637,6 +1702,216 @@ __global__ __launch_bounds__(256) void trsv_update_bwd_kernel(const double* __re
     if (wave == 0 && j < cols) y[j] -= part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
 }
 
+// ---- [r3] the backward sweep with the wide gemv OFF the chain: one launch per diagonal block -------------------------------
+// Block b can be solved as soon as x_{b+1} has been applied to ITS OWN w columns (a w x wn piece of the gemv, 2 MB at nb = 512);
+// the rest of that gemv (the columns left of block b) is only needed by later launches.  One launch therefore holds
+//   workgroup 0            the substitution on block b (the pipelined solver above), which first waits - bounded - until
+//   workgroups 1 .. w/64   have applied x_{b+1} to the columns of block b (64 columns each, counted on a device word), while
+//   the other workgroups   apply x_{b+1} to everything left of block b, beside the substitution.
+// Everything in the launch depends on x_{b+1} alone (the previous launch); nobody but workgroup 0 waits, and it waits only for
+// workgroups that wait for nothing, so the launch drains whatever order the dispatcher takes.  The chain per block is
+// launch + piece (~3 us) + substitution instead of substitution + launch + a gemv over up to 130 MB (18 us at N = 32768).
+// If the count does not arrive within the bound the solution is poisoned with NaN (the callers' residual checks fail loudly).
+__global__ __launch_bounds__(320) void trsv_bwd_fused_kernel(const double* __restrict__ L, int64_t lda, double* __restrict__ v,
+                                                             int64_t r0, int w, int wn, unsigned* __restrict__ counter,
+                                                             unsigned target, const double* __restrict__ warm, int warm_w) {
+    __shared__ double ys[TRSV_PIPE_MAXW];  // solver: the block's right-hand side / solution; update: x_{b+1}
+    __shared__ double Tn[IB][IB];
+    __shared__ double part[4][IB];
+    __shared__ int gave_up;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x != 0) {
+        // ---- gemv workgroups: 64 columns each, the piece (columns of block b) first in block order
+        const int np = w / IB;
+        const int64_t c = (int64_t)blockIdx.x - 1;
+        const bool piece = c < np;
+        const int64_t j = (piece ? r0 + c * IB : (c - np) * IB) + lane;          // rest: columns [0, r0)
+        if (!piece) trsv_warm_l2(warm, lda, warm_w, v);
+        const double* __restrict__ x = v + r0 + w;
+        for (int i = tid; i < wn; i += 320) ys[i] = x[i];
+        __syncthreads();
+        double s = 0.0;
+        if (wave < 4) {
+            const double* __restrict__ Lb = L + (r0 + w) * lda + j;
+            for (int i0 = wave; i0 < wn; i0 += 64) {                           // wn is a multiple of 64: 16 independent loads per trip
+                double t[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t[u] = Lb[(int64_t)(i0 + 4 * u) * lda];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s += t[u] * ys[i0 + 4 * u];
+            }
+            part[wave][lane] = s;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            v[j] -= part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+            if (piece) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");             // the wave's stores before the count
+                if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+    // ---- workgroup 0: the substitution (trsv_diag_bwd_pipe_kernel with the wait in front of the first read of y)
+    const double* __restrict__ Ld = L + r0 * lda + r0;
+    double* __restrict__ y = v + r0;
+    const bool solver = wave == 0;
+    const int q = wave - 1;
+    const int st = tid - 64;
+    if (!solver) {
+        const int c0 = w - IB;
+#pragma unroll
+        for (int u = 0; u < IB * IB / 256; ++u) {
+            const int idx = st + 256 * u;
+            Tn[idx >> 6][idx & 63] = Ld[(int64_t)(c0 + (idx >> 6)) * lda + c0 + (idx & 63)];
+        }
+    }
+    if (tid == 0) {
+        int failed = 0;
+        if (wn > 0) {
+            failed = 1;
+            for (int guard = 0; guard < (1 << 22); ++guard) {
+                if ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { failed = 0; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        gave_up = failed;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                         // the pieces' stores, not this CU's stale lines
+    const bool bad = gave_up != 0;
+    for (int i = tid; i < w; i += 320) ys[i] = bad ? __builtin_nan("") : y[i];
+    __syncthreads();
+    double pend = 0.0;                     // solver: sum_{i >= c0 + 64} L[i][c0 + lane] x[i]
+    for (int c0 = w - IB; c0 >= 0; c0 -= IB) {
+        const int c1 = c0 - IB;
+        const bool more = c1 >= 0;
+        double tn[IB * IB / 256], xr[16], snext = 0.0;
+        if (solver) {
+            double b = ys[c0 + lane] - pend;
+            const double rd = 1.0 / Tn[lane][lane];
+#pragma unroll 8
+            for (int k = IB - 1; k >= 0; --k) {
+                const double coef = Tn[k][lane] * readlane_f64(rd, k);
+                const double bk = readlane_f64(b, k);
+                b = (lane < k) ? fma(-coef, bk, b) : b;
+            }
+            ys[c0 + lane] = b * rd;
+        } else if (more) {
+#pragma unroll
+            for (int u = 0; u < IB * IB / 256; ++u) {          // next diagonal tile
+                const int idx = st + 256 * u;
+                tn[u] = Ld[(int64_t)(c1 + (idx >> 6)) * lda + c1 + (idx & 63)];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)                       // coupling tile: rows c0 + 16 q + u, column c1 + lane
+                xr[u] = Ld[(int64_t)(c0 + 16 * q + u) * lda + c1 + lane];
+            for (int i0 = c0 + IB + q; i0 < w; i0 += 64) {     // rows solved before this sub-block
+                double t[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t[u] = Ld[(int64_t)(i0 + 4 * u) * lda + c1 + lane];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) snext += t[u] * ys[i0 + 4 * u];
+            }
+        }
+        __syncthreads();
+        if (!solver && more) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) snext += xr[u] * ys[c0 + 16 * q + u];
+            part[q][lane] = snext;
+#pragma unroll
+            for (int u = 0; u < IB * IB / 256; ++u) {
+                const int idx = st + 256 * u;
+                Tn[idx >> 6][idx & 63] = tn[u];
+            }
+        }
+        __syncthreads();
+        if (solver && more) pend = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+    }
+    for (int i = tid; i < w; i += 320) y[i] = ys[i];
+}
+
+// ---- [r3] the backward sweep with INVERTED diagonal blocks: no substitution chain at all ---------------------------------------
+// With D_b = L_bb^-1 (ensure_dinv: all blocks in 7 batched launches, cached on the factor and shared with the variance path)
+// the solve of block b is a 512 x 512 transposed matrix-vector product, x_b = D_b^T r_b - eight workgroups instead of one
+// workgroup's 8 x 64 dependent steps.  One launch per block, three roles by workgroup index:
+//   solve  (w/64)   wait - bounded - for the pieces' count, then x_b[j] = sum_{i >= j} D_b[i][j] r_b[i] for 64 columns each
+//   piece  (w/64)   r_b = y_b - L[b+1 rows][b cols]^T x_{b+1} for 64 columns each -> scratch R, counted on a device word
+//   rest            y[j] -= L[b+1 rows][j]^T x_{b+1} for the columns left of block b (HBM-bound, beside the other two)
+// Only the solve workgroups wait, and only for workgroups that wait for nothing.  The next launch starts when this one has
+// drained, so a block costs max(rest, piece + solve) + one launch: the sweep is the 4 N^2 bytes of L through HBM once.
+// If the count does not arrive within the bound the solution is poisoned with NaN (the callers' residual checks fail loudly).
+__global__ __launch_bounds__(256) void trsv_bwd_dinv_kernel(const double* __restrict__ L, int64_t lda, double* __restrict__ v,
+                                                            int64_t r0, int w, int wn, const double* __restrict__ Dn, int64_t ldd,
+                                                            double* __restrict__ R, unsigned* __restrict__ counter, unsigned target,
+                                                            const double* __restrict__ warm, int warm_w) {
+    __shared__ double xs[TRSV_PIPE_MAXW];
+    __shared__ double part[4][IB];
+    __shared__ int gave_up;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ns = w / IB;
+    if ((int)blockIdx.x < ns) {
+        // ---- solve: columns [64 c, 64 c + 64) of the block
+        const int c = blockIdx.x;
+        if (tid == 0) {
+            int failed = 1;
+            for (int guard = 0; guard < (1 << 22); ++guard) {
+                if ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { failed = 0; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            gave_up = failed;
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                     // the pieces' stores, not this CU's stale lines
+        const bool bad = gave_up != 0;
+        for (int i = 64 * c + tid; i < w; i += 256) xs[i] = R[i];
+        __syncthreads();
+        const int j = 64 * c + lane;
+        const double* __restrict__ Db = Dn + j;
+        double s = 0.0;
+        for (int i0 = 64 * c + wave; i0 < w; i0 += 64) {                       // D is lower triangular: rows from the column's own tile down
+            double t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = Db[(int64_t)(i0 + 4 * u) * ldd];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += t[u] * xs[i0 + 4 * u];
+        }
+        part[wave][lane] = s;
+        __syncthreads();
+        if (wave == 0) v[r0 + j] = bad ? __builtin_nan("") : -(part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);   // Dn = -D
+        return;
+    }
+    // ---- piece / rest: 64 columns each, apply x_{b+1} (nothing for the last block of the matrix: wn == 0)
+    const int64_t g = (int64_t)blockIdx.x - ns;
+    const bool piece = g < ns;
+    const int64_t j = (piece ? r0 + g * IB : (g - ns) * IB) + lane;
+    if (!piece) trsv_warm_l2(warm, lda, warm_w, v);
+    const double* __restrict__ x = v + r0 + w;
+    for (int i = tid; i < wn; i += 256) xs[i] = x[i];
+    __syncthreads();
+    double s = 0.0;
+    const double* __restrict__ Lb = L + (r0 + w) * lda + j;
+    for (int i0 = wave; i0 < wn; i0 += 64) {                                   // wn is a multiple of 64: 16 independent loads per trip
+        double t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = Lb[(int64_t)(i0 + 4 * u) * lda];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += t[u] * xs[i0 + 4 * u];
+    }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0) {
+        const double r = v[j] - (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+        if (piece) {
+            R[j - r0] = r;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                 // the wave's stores before the count
+            if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            v[j] = r;
+        }
+    }
+}
+
 static void launch_trsv_update(hipStream_t stream, const double* L, int64_t lda, double* v, int64_t r0, int w, int64_t first,
                                int64_t count, int trans, const double* warm, int warm_w) {
     if (count <= 0) return;
@@ -1671,12 +1946,45 @@ static int trsv_sweeps(mgpi_ctx* ctx, const mgpi_mat* Lm, double* v, int which) 
         const int w1 = (int)((pn - r1 < nb) ? (pn - r1) : nb);
         launch_trsv_update(ctx->stream, L, lda, v, r0, w, r1, pn - r1, 0, w1 > 0 ? L + r1 * lda + r1 : nullptr, w1);
     }
+    // [r3] backward: one fused launch per block (trsv_bwd_fused_kernel); MGPI_TRSV_FUSED=0 keeps the two launches per block
+    static const int fused_env = getenv("MGPI_TRSV_FUSED") ? atoi(getenv("MGPI_TRSV_FUSED")) : 1;
+    const bool fused = fused_env != 0 && nb <= TRSV_PIPE_MAXW && nb % IB == 0;
+    // MGPI_TRSV_DINV=1 (default): inverted diagonal blocks (trsv_bwd_dinv_kernel); 0: the substitution kernels
+    // Only for factors whose diagonal spans at most MGPI_TRSV_DINV_RATIO (default 1e4, i.e. cond K up to ~1e8 by that
+    // measure; the parity contract ends at 1e7): a product with an explicit inverse has a backward error of ~cond(L_bb) eps
+    // instead of eps, and at cond K ~ 5e15 (tests/test_gpu_configs.py::test_pivot_tolerance_is_configurable) that showed:
+    // 6e-13 against < 1e-13.  A factor whose status was never read (range unknown) takes the substitution.
+    static const int dinv_env = getenv("MGPI_TRSV_DINV") ? atoi(getenv("MGPI_TRSV_DINV")) : 1;
+    static const double dinv_ratio = getenv("MGPI_TRSV_DINV_RATIO") ? atof(getenv("MGPI_TRSV_DINV_RATIO")) : 1e4;
+    const bool by_inverse = fused && dinv_env != 0 && (which & 2) && Lm->diag_min > 0.0 && Lm->diag_max <= dinv_ratio * Lm->diag_min;
+    if (by_inverse) MGPI_TRY(ensure_dinv(ctx, Lm));
+    unsigned* piece_count = reinterpret_cast<unsigned*>(ctx->d_scal + 8080);
+    double* piece_r = ctx->d_scal + 5000;                        // r_b of the block being solved (<= 1024 doubles)
+    unsigned pieces_done = 0;
+    if (fused && (which & 2)) MGPI_HIP_TRY(hipMemsetAsync(piece_count, 0, sizeof(unsigned), ctx->stream));
     for (int64_t b = (which & 2) ? nblk - 1 : -1; b >= 0; --b) {
         const int64_t r0 = b * nb;
         const int w = (int)((pn - r0 < nb) ? (pn - r0) : nb);
-        launch_trsv_diag(ctx->stream, L + r0 * lda + r0, lda, v + r0, w, 1);
         const int wp = (int)((r0 < nb) ? r0 : nb);
-        launch_trsv_update(ctx->stream, L, lda, v, r0, w, 0, r0, 1, wp > 0 ? L + (r0 - wp) * lda + (r0 - wp) : nullptr, wp);
+        const double* warm = wp > 0 ? L + (r0 - wp) * lda + (r0 - wp) : nullptr;
+        if (by_inverse) {
+            const int wn = (b == nblk - 1) ? 0 : (int)((pn - (r0 + w) < nb) ? (pn - (r0 + w)) : nb);   // the block solved just before
+            const int64_t groups = (wn > 0 ? r0 : 0) / IB + 2 * (w / IB);                               // rest + piece + solve
+            pieces_done += (unsigned)(w / IB);
+            hipLaunchKernelGGL(trsv_bwd_dinv_kernel, dim3((unsigned)groups), dim3(256), 0, ctx->stream, L, lda, v, r0, w, wn,
+                               mgpi_dinv_block(Lm, b), nb, piece_r, piece_count, pieces_done, warm, wp);
+            continue;
+        }
+        if (fused) {
+            const int wn = (b == nblk - 1) ? 0 : (int)((pn - (r0 + w) < nb) ? (pn - (r0 + w)) : nb);   // the block solved just before
+            const int64_t groups = wn > 0 ? (r0 + w) / IB : 0;
+            if (wn > 0) pieces_done += (unsigned)(w / IB);
+            hipLaunchKernelGGL(trsv_bwd_fused_kernel, dim3((unsigned)(1 + groups)), dim3(320), 0, ctx->stream, L, lda, v, r0, w, wn,
+                               piece_count, pieces_done, warm, wp);
+            continue;
+        }
+        launch_trsv_diag(ctx->stream, L + r0 * lda + r0, lda, v + r0, w, 1);
+        launch_trsv_update(ctx->stream, L, lda, v, r0, w, 0, r0, 1, warm, wp);
     }
     MGPI_HIP_TRY(hipGetLastError());
     return 0;

@@ -341,6 +341,7 @@ static int mat_alloc_impl(mgpi_ctx* ctx, int64_t rows, int64_t cols, int wide, m
     m->ld = m->pcols;
     m->owns = 1;
     m->factored = 0;
+    m->diag_min = m->diag_max = 0.0;
     size_t bytes = (size_t)m->prows * (size_t)m->pcols * sizeof(double);
     if (int rc = pool_alloc(ctx, bytes, &m->d, &m->alloc_bytes)) {
         delete m;
@@ -373,6 +374,7 @@ static void mat_drop_dinv(mgpi_mat* m) {
 // the contents of m are about to change: it is no longer a factor and its cached inverse blocks are stale
 void mgpi_mat_invalidate(mgpi_mat* m) {
     m->factored = 0;
+    m->diag_min = m->diag_max = 0.0;
     mat_drop_dinv(m);
 }
 
@@ -406,6 +408,8 @@ extern "C" int mgpi_mat_view(const mgpi_mat* m, int64_t r0, int64_t c0, int64_t 
     // a window of a factor is a factor only when it is the whole (padded) matrix; the parent's cache of inverse
     // diagonal blocks is never shared (a view that needs one builds and owns its own)
     v->factored = (m->factored && r0 == 0 && c0 == 0 && rows == m->prows && cols == m->pcols) ? 1 : 0;
+    v->diag_min = v->factored ? m->diag_min : 0.0;
+    v->diag_max = v->factored ? m->diag_max : 0.0;
     v->dinv = nullptr;
     v->dinv_nb = 0;
     v->dinv_bytes = 0;
@@ -449,6 +453,7 @@ extern "C" int mgpi_mat_wrap(mgpi_ctx* ctx, void* devptr, int64_t rows, int64_t 
     v->d = (double*)devptr;
     v->owns = 0;
     v->factored = factored;
+    v->diag_min = v->diag_max = 0.0;
     *out = v;
     return 0;
 }
@@ -480,6 +485,7 @@ extern "C" int mgpi_mat_upload(mgpi_mat* m, const double* host, int64_t host_ld)
                                   m->ctx->stream));
     MGPI_HIP_TRY(hipStreamSynchronize(m->ctx->stream));
     m->factored = 0;
+    m->diag_min = m->diag_max = 0.0;
     mat_drop_dinv(m);
     return 0;
 }
@@ -503,6 +509,8 @@ extern "C" int mgpi_mat_copy(mgpi_ctx* ctx, const mgpi_mat* src, mgpi_mat* dst) 
     MGPI_HIP_TRY(hipMemcpy2DAsync(dst->d, (size_t)dst->ld * sizeof(double), src->d, (size_t)src->ld * sizeof(double),
                                   (size_t)c * sizeof(double), (size_t)r, hipMemcpyDeviceToDevice, ctx->stream));
     dst->factored = src->factored;
+    dst->diag_min = src->diag_min;
+    dst->diag_max = src->diag_max;
     mat_drop_dinv(dst);          // inverse blocks of whatever dst held before
     return 0;
 }
@@ -650,6 +658,7 @@ extern "C" int mgpi_mat_unscale(mgpi_ctx* ctx, mgpi_mat* m, const mgpi_mat* s) {
                        m->d, m->ld, m->rows, s->d);
     MGPI_HIP_TRY(hipGetLastError());
     m->factored = 0;
+    m->diag_min = m->diag_max = 0.0;
     mat_drop_dinv(m);
     return 0;
 }

@@ -42,7 +42,7 @@ struct mgpi_ctx {
                                   // column update, 4 big update of the multi-rhs forward solve (variance), 5 fused predict mean,
                                   // 6 backward sweep of mgpi_posv_dev (what the solve still costs after the factorisation)
     int* d_info;                  // device: first failing pivot (0 = none)
-    double* d_scal;               // device scratch, 8192 doubles: [0] logdet, [1] status accumulator, [64, 64 + 64*64 + 64) panel images, [8000] barrier token, [8064] progress counter of the merged trailing update, [8072] stream-overlap handshake
+    double* d_scal;               // device scratch, 8192 doubles: [0] logdet, [1] status accumulator, [64, 64 + 64*64 + 64) panel images, [8000] barrier token, [8064] progress counter of the merged trailing update, [8072] stream-overlap handshake, [8080] piece counter of the fused backward substitution
     void* h_pinned;               // 64 KB of pinned host memory: small read-backs (status words, log-likelihood values) land here
                                   // without the staging copy a pageable destination costs (MGPI_PINNED_BYTES)
     double* d_diag;               // diag(K) before factoring (pivot threshold), grown on demand
@@ -63,8 +63,9 @@ struct mgpi_mat {
     double* d;                    // device pointer to element (0,0)
     int owns;
     int factored;                 // set by potrf
+    double diag_min, diag_max;    // smallest / largest L_ii of the factor as the last status read saw them (0: unknown) - chol.hip, trsv_sweeps
     size_t alloc_bytes;           // owners: size of the device block (>= prows*pcols*8 when it came from the pool)
-    double* dinv;                 // -(L_bb)^-1 of the factor's nb x nb diagonal blocks, block b at rows [b nb, ..), ld = dinv_nb;
+    double* dinv;                 // -(L_bb)^-1 of the factor's nb x nb diagonal blocks, block b at b nb (nb + 1), row stride nb = dinv_nb;
     int64_t dinv_nb;              //   built on demand by the variance path (chol.hip), dropped when the matrix is refactored
     size_t dinv_bytes;
 };

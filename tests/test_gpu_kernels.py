@@ -309,6 +309,43 @@ def test_trtri_neg_strided_batch(ctx, w, batch, row_step, col_step):
         _lib.check(ctx.lib.mgpi_trtri_neg_dev(ctx.handle, dA.handle, r0, c0, row_step, col_step, w, batch + 50, out.handle))
 
 
+@pytest.mark.parametrize('n', [700, 5000, 9000])
+def test_backward_sweep_by_inverted_blocks_against_substitution(ctx, n):
+    """[r3] the backward sweep of a single-right-hand-side solve takes the inverted diagonal blocks (trsv_bwd_dinv_kernel) when the
+    factorisation's status read-back says the factor's diagonal spans at most 1e4, the substitution kernels otherwise - among
+    others for a factor whose status this library never read.  A second handle over the SAME device memory (mgpi_mat_wrap: range
+    unknown) therefore solves by substitution: the two alphas agree to 1e-13 of |alpha| and both leave a residual below 1e-11."""
+    rng = np.random.default_rng(n)
+    x = rng.random((n, 3))
+    f = np.sin(3 * x[:, 0]) + x[:, 1] * x[:, 2]
+    terms = (mgpi.SquaredExponentialKernel(1.0, 0.2, 0.2, 0.2) + mgpi.WhiteNoiseKernel(1e-2)).terms()
+    desc, count = _lib.make_terms(terms)
+    X = _lib.DeviceMatrix.from_host(ctx, x)
+    K = _lib.DeviceMatrix(ctx, n, n, wide=True)
+    _lib.check(ctx.lib.mgpi_cov_matrix_dev(ctx.handle, X.handle, None, desc, count, 1, K.handle))
+    _lib.check(ctx.lib.mgpi_potrf_dev(ctx.handle, K.handle, None))
+    rows, cols, ld = K.shape3()
+    fpad = np.zeros(ld)                                     # the wrapped handle is the PADDED square (unit diagonal beyond n)
+    fpad[:n] = f
+    a1, a2 = _lib.DeviceMatrix.from_host(ctx, f), _lib.DeviceMatrix.from_host(ctx, fpad)
+    _lib.check(ctx.lib.mgpi_potrs_dev(ctx.handle, K.handle, a1.handle))
+    h = ctypes.c_void_p()
+    _lib.check(ctx.lib.mgpi_mat_wrap(ctx.handle, K.devptr, ld, ld, ld, 1, ctypes.byref(h)))
+    try:
+        _lib.check(ctx.lib.mgpi_potrs_dev(ctx.handle, h, a2.handle))
+    finally:
+        ctx.lib.mgpi_mat_free(h)
+    b1, b2 = a1.to_host().reshape(-1), a2.to_host().reshape(-1)
+    assert np.all(b2[n:] == 0.0)
+    b2 = b2[:n]
+    assert np.all(np.isfinite(b1)) and np.all(np.isfinite(b2))
+    assert np.max(np.abs(b1 - b2)) < 1e-13 * np.max(np.abs(b2))
+    if n <= 5000:
+        Kh = oracle.x2cov_chunked([oracle.term_se(1.0, 0.2, 0.2, 0.2), oracle.term_white(1e-2)], x, x, rows=max(1, 262144 // n))
+        for b in (b1, b2):
+            assert np.max(np.abs(Kh @ b - f)) < 1e-11 * max(1.0, np.max(np.abs(f)))
+
+
 @pytest.mark.parametrize('env', [{'MGPI_NO_LOOKAHEAD': '1'}, {'MGPI_POOL_MB': '0'},
                                  {'MGPI_SUPER_PANELS': '1', 'MGPI_SUPER_MIN': '512'}, {'MGPI_SUPER_PANELS': '2', 'MGPI_SUPER_MIN': '512'},
                                  {'MGPI_VAR_DINV': '0'},
@@ -322,7 +359,8 @@ def test_trtri_neg_strided_batch(ctx, w, batch, row_step, col_step):
                                  {'AMD_SERIALIZE_KERNEL': '3', 'MGPI_MERGED_MIN': '0', 'MGPI_SUPER_MIN': '512'},
                                  {'HIP_LAUNCH_BLOCKING': '1', 'MGPI_MERGED_MIN': '0', 'MGPI_SUPER_MIN': '512'},
                                  {'GPU_MAX_HW_QUEUES': '1', 'MGPI_MERGED_MIN': '0', 'MGPI_SUPER_MIN': '512'},
-                                 {'MGPI_LL_CHUNK_BYTES': '12000000'}, {}],
+                                 {'MGPI_LL_CHUNK_BYTES': '12000000'}, {'MGPI_TRSV_DINV': '0'}, {'MGPI_TRSV_DINV': '0', 'MGPI_TRSV_FUSED': '0'},
+                                 {'MGPI_DINV_HALVING': '0'}, {}],
                          ids=lambda e: ','.join('%s=%s' % kv for kv in e.items()) or 'defaults')
 def test_developer_switch_variants(env):
     """the schedule thresholds and the few alternative forms that ship behind an environment switch (DESIGN.md section c)
@@ -332,7 +370,8 @@ def test_developer_switch_variants(env):
     MFMA form of predict-mean, 128-wide tiles for skinny updates; environments that serialise kernels (AMD_SERIALIZE_KERNEL,
     HIP_LAUNCH_BLOCKING, one hardware queue) with a threshold that WOULD engage the merged trailing update - the library must
     notice and take the separate column update instead of stalling in its bounded wait; a log-likelihood batch split into
-    chunks.  (The measured losers of rounds 1-2 - ping-pong and
+    chunks; the backward sweep of the solve by substitution (fused launch / two launches per block) instead of inverted diagonal
+    blocks, and those inverses by the round-2 block substitution instead of recursive halving.  (The measured losers of rounds 1-2 - ping-pong and
     register-staged gemm, round-1 panel kernels, left-looking steps, matrix-pipe factorisation - are gone, round 3.)"""
     import os
     import subprocess
