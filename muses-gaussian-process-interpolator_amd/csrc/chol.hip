@@ -742,6 +742,13 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     MGPI_TRY(forward_columns(0, wc));
     if (lookahead) MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
     bool panel_on_side = false;                                  // is the current super-panel the product of stream2?
+    // [r3] In the un-merged look-ahead steps the main stream's update of the rest waits until the next panel's block column
+    // has been updated on the second stream: started together, the big update took the CUs the skinny one - which is on the
+    // chain - needed (rocprofv3 timeline at N = 8192, profiles/r03_potrf_n8192_timeline.md: 250 us per column update beside
+    // the big one, 82 us ahead of it).  potrf N = 8192 6.87 -> 6.6 ms, N = 12288 15.4 -> 14.9, loglikelihood N = 7933 7.05 -> 6.8.
+    // Not with riders (their rows make the column update long enough to delay the big one; C2 12.15 -> 12.28 ms).
+    static const int col_first_env = getenv("MGPI_POTRF_COLFIRST") ? atoi(getenv("MGPI_POTRF_COLFIRST")) : 1;
+    const bool col_first = col_first_env != 0 && pm == 0;
     for (int64_t r0 = 0; r0 < pn && !tall;) {
         const int64_t w = wc;                                 // super-panel k (already factored)
         const int64_t t = pn - r0 - w;                        // trailing size
@@ -805,6 +812,7 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
             mgpi_prof_begin(ctx, 3);
             int rc = mgpi_launch_gemm(ctx, 0, 0, 0, t + pm, w1, w, P, lda, P, lda, A + r1 * lda + r1, lda);    // rider rows follow the square's
             mgpi_prof_end(ctx, 3);
+            if (col_first) MGPI_HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
             if (rc == 0) rc = factor_super(r1, w1, true);
             if (rc == 0) rc = forward_columns(r1, r1 + w1);
             ctx->stream = main_stream;
@@ -813,6 +821,7 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
             panel_on_side = true;
             // main stream: the rest of the trailing update (lower tiles): A[r2:pn, r2:pn] -= P[w1:] P[w1:]^T
             if (t2 > 0) {
+                if (col_first) MGPI_HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
                 mgpi_prof_begin(ctx, 0);
                 const double* P2 = P + w1 * lda;
                 MGPI_TRY(mgpi_launch_gemm(ctx, 0, 0, 1, t2, t2, w, P2, lda, P2, lda, A + (r1 + w1) * lda + (r1 + w1), lda));
