@@ -178,6 +178,62 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__
     PT_FLUSH(1);
 }
 
+// [r3] The rows launch of a SPLIT step (mode 2 of panel_step_kernel) with NU units of work per workgroup, as a kernel of its
+// own (panel_step_kernel keeps its register budget): rows != 0: row blocks 1 + NU p .. NU + NU p below the diagonal block, their
+// substitution chains interleaved (trsm_acc_mxn), the factor's images from F; rows == 0: update-role tiles NU p .. NU p + NU - 1
+// (ntiles in all).  A unit index beyond the last one is clamped to it: the same loads, the same arithmetic, the same values
+// stored twice by the same workgroup.  The split steps run beside the trailing update of a large matrix: 1/NU of the
+// workgroups and image loads, and less time in which these latency-bound workgroups keep CU slots from the big kernel.
+// Measured (bench.py C3, same box, NU = 1 / 2 / 4): 258.8 / 258.2 / 258.7 ms per step, the trailing update's in-region time
+// 177.9 / 176.1 / 176.0 ms (0.799 / 0.807 / 0.808 of peak) - four units spill (256 VGPRs + 21), two ship; C4 1669.5 -> 1664.2 ms.
+template <int NU>
+__global__ __launch_bounds__(256, 2) void panel_units_kernel(double* __restrict__ A, int64_t lda, int64_t c0, int has_prev, int nfused,
+                                                           int rows, const double* __restrict__ F, int ntiles) {
+    __shared__ panel_lds s;
+    MGPI_CHAIN_PRIO();
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t cp = c0 - IB, c1 = c0 + IB;
+    panel_double4_t acc[NU][4];
+    if (!rows) {
+        double* C[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            int t = NU * (int)blockIdx.x + u, ti, tj;
+            t = t < ntiles ? t : ntiles - 1;
+            panel_rest_decode(t, nfused - 1, ti, tj);
+            C[u] = A + (c1 + (int64_t)IB * ti) * lda + c1 + (int64_t)IB * tj;
+            panel_load(acc[u], C[u], lda, w, g, c, false);
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int64_t ro = (C[u] - A) / lda, co = (C[u] - A) % lda;          // the tile's first row / column
+            panel_gemm_nt(acc[u], A + (ro + 16 * w + c) * lda + cp + 2 * g, A + (co + c) * lda + cp + 2 * g, lda, 0, 4);
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) panel_store(acc[u], C[u], lda, w, g, c);
+        return;
+    }
+    double* out[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        int b = 1 + NU * (int)blockIdx.x + u;
+        b = b < nfused ? b : nfused - 1;
+        const int64_t r = c0 + (int64_t)IB * b;
+        panel_load(acc[u], A + r * lda + c0, lda, w, g, c, false);
+        out[u] = A + (r + 16 * w + c) * lda + c0;
+    }
+    for (int i = tid; i < IB * IB; i += 256) (&s.Lt[0][0])[i] = F[i];
+    if (tid < IB) s.invd[tid] = F[IB * IB + tid];
+    if (has_prev) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) panel_gemm_nt(acc[u], out[u] - c0 + cp + 2 * g, A + (c0 + c) * lda + cp + 2 * g, lda, 0, 4);
+    }
+    __syncthreads();
+    panel_trsm_images(s, tid);
+    trsm_acc_mxn<0, NU>::run(acc, s, w, g, c, out);
+}
+
 // one step: diagonal block at (c0, c0) of the matrix A (c0 absolute), `rows_below` rows below the block, the panel ends at
 // column panel_end; has_prev: the columns [c0 - 64, c0) of this panel were solved by the previous step and still have to be
 // applied to everything right of them.  split: two launches (diagonal block, then the rows) instead of one
@@ -194,7 +250,14 @@ static int launch_panel_step(mgpi_ctx* ctx, double* A, int64_t lda, int64_t c0, 
     } else {
         hipLaunchKernelGGL(panel_step_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused, rest_cols, pivot_base,
                            diag0, ctx->d_info, S, ctx->pivot_tol, 1, F, (int64_t)0, (int64_t)0, (int64_t)0);
-        if (nfused - 1 + nrest > 0)
+        // [r3] several units of work per workgroup (panel_units_kernel): the rows, then the update-role tiles; MGPI_PANEL_PAIRS=0 keeps mode 2
+        static const int units = getenv("MGPI_PANEL_PAIRS") ? atoi(getenv("MGPI_PANEL_PAIRS")) : 2;
+        if (units >= 2 && nfused - 1 >= 2) {
+            const int nrow = nfused - 1;
+            hipLaunchKernelGGL(panel_units_kernel<2>, dim3((unsigned)((nrow + 1) / 2)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused, 1, F, 0);
+            if (nrest > 0)
+                hipLaunchKernelGGL(panel_units_kernel<2>, dim3((unsigned)((nrest + 1) / 2)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused, 0, F, (int)nrest);
+        } else if (nfused - 1 + nrest > 0)
             hipLaunchKernelGGL(panel_step_kernel, dim3((unsigned)(nfused - 1 + nrest)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev,
                                nfused, rest_cols, pivot_base, diag0, ctx->d_info, S, ctx->pivot_tol, 2, F, (int64_t)0, (int64_t)0, (int64_t)0);
     }

@@ -152,6 +152,7 @@ typedef double panel_double4_t __attribute__((ext_vector_type(4)));
 struct __attribute__((aligned(32))) panel_lds {
     double raw[2][IB][4];      // potf2: raw[buf][row][t] = entry (row, K + t) of the current round, two rounds in flight
     double zraw[4][16][4];     // trsm: the same, private to each wave (its 16 rows)
+    double zrawn[3][4][16][4]; // ... of the 2nd - 4th row block of a workgroup that holds several (trsm_acc_mxn)
     double Lt[IB][IB];         // Lt[k][m] = L[m][k] for m >= k (the factor, transposed: B operand of the substitution), 0 above
     double invd[IB];           // 1 / L[k][k]
     double dtol[IB];           // pivot thresholds
@@ -368,6 +369,52 @@ struct trsm_acc_mx {
                 if (n >= QK) acc[n] = PANEL_MFMA(y, -s.Lt[K + g][16 * n + c], acc[n]);
             __asm__ volatile("" ::: "memory");  // the next round's strip writes stay behind this round's read
             trsm_acc_mx<K + 4>::run(acc, s, w, g, c, outrow);
+        }
+    }
+};
+
+// [r3] NBLK independent 64-row blocks per workgroup, their dependent chains interleaved: the rows launches of the split steps
+// (large matrices, beside the trailing update) are latency-bound chains of four dependent matrix instructions per round, so
+// further blocks ride along in the same issue slots - 1/NBLK of the workgroups and of the LDS image loads, and less time in
+// which those workgroups keep a CU slot from the trailing update.
+template <int K, int NBLK>
+struct trsm_acc_mxn {
+    static __device__ __forceinline__ void run(panel_double4_t (&acc)[NBLK][4], panel_lds& s, int w, int g, int c, double* (&out)[NBLK]) {
+        constexpr int QK = K / 16, KL = K % 16, R = K / 4;
+        if (c >= KL && c < KL + 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s.zraw[w][g + 4 * r][c - KL] = acc[0][QK][r];
+#pragma unroll
+                for (int b = 1; b < NBLK; ++b) s.zrawn[b - 1][w][g + 4 * r][c - KL] = acc[b][QK][r];
+            }
+        }
+        __asm__ volatile("" ::: "memory");
+        double a[NBLK], y0[NBLK], y[NBLK];
+        a[0] = s.zraw[w][c][g];
+#pragma unroll
+        for (int b = 1; b < NBLK; ++b) a[b] = s.zrawn[b - 1][w][c][g];
+        const double dg = s.dgA[R][c & 3][g], t = s.tA[R][c & 3][g];
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) y0[b] = PANEL_MFMA4(dg, a[b], 0.0);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) y[b] = PANEL_MFMA4(t, y0[b], y0[b]);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) y[b] = PANEL_MFMA4(t, y[b], y0[b]);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) y[b] = PANEL_MFMA4(t, y[b], y0[b]);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) out[b][K + g] = y[b];
+        if constexpr (K + 4 < IB) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (n >= QK) {
+                    const double lt = -s.Lt[K + g][16 * n + c];
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b) acc[b][n] = PANEL_MFMA(y[b], lt, acc[b][n]);
+                }
+            __asm__ volatile("" ::: "memory");
+            trsm_acc_mxn<K + 4, NBLK>::run(acc, s, w, g, c, out);
         }
     }
 };

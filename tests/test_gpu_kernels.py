@@ -350,7 +350,8 @@ def test_backward_sweep_by_inverted_blocks_against_substitution(ctx, n):
                                  {'MGPI_SUPER_PANELS': '1', 'MGPI_SUPER_MIN': '512'}, {'MGPI_SUPER_PANELS': '2', 'MGPI_SUPER_MIN': '512'},
                                  {'MGPI_VAR_DINV': '0'},
                                  {'MGPI_TRSM_SUPER': '1', 'MGPI_TRSM_SUPER_MIN': '512'}, {'MGPI_TRSM_SUPER': '4', 'MGPI_TRSM_SUPER_MIN': '512'},
-                                 {'MGPI_PANEL_STEP_ROWS': '0'}, {'MGPI_PANEL_STEP_ROWS': '1000000', 'MGPI_SUPER_MIN': '512'},
+                                 {'MGPI_PANEL_STEP_ROWS': '0'}, {'MGPI_PANEL_STEP_ROWS': '0', 'MGPI_PANEL_PAIRS': '0'},
+                                 {'MGPI_PANEL_STEP_ROWS': '1000000', 'MGPI_SUPER_MIN': '512'},
                                  {'MGPI_POTRF_MERGED': '0'}, {'MGPI_TAIL_ROWS': '0'}, {'MGPI_TAIL_ROWS': '4096', 'MGPI_SUPER_MIN': '512'},
                                  {'MGPI_PANEL_INNER': '512'}, {'MGPI_PANEL_INNER': '128', 'MGPI_PANEL_INNER_ROWS': '0'},
                                  {'MGPI_PANEL_INNER': '256', 'MGPI_PANEL_INNER_ROWS': '0', 'MGPI_MERGED_MIN': '0'},
@@ -365,7 +366,7 @@ def test_backward_sweep_by_inverted_blocks_against_substitution(ctx, n):
 def test_developer_switch_variants(env):
     """the schedule thresholds and the few alternative forms that ship behind an environment switch (DESIGN.md section c)
     compute the same results: no look-ahead, no buffer pool, 1 / 2 panels per trailing update (with a threshold small enough
-    for the two-level schedule to engage), the panel step as one launch everywhere / two launches everywhere, the separate
+    for the two-level schedule to engage), the panel step as one launch everywhere / split everywhere (rows two blocks per workgroup, or one), the separate
     column update instead of the merged trailing update, tail and sub-panel thresholds, the general kernel-term loop, the
     MFMA form of predict-mean, 128-wide tiles for skinny updates; environments that serialise kernels (AMD_SERIALIZE_KERNEL,
     HIP_LAUNCH_BLOCKING, one hardware queue) with a threshold that WOULD engage the merged trailing update - the library must
