@@ -515,9 +515,14 @@ def main():
         else:
             ctx.sync()
 
+    c5 = (not distributed) and args.workload.startswith('c5')
+    slot = 4 if c5 else 0      # the dominant kernel: NN update gemm of the variance solve (C5) / lower syrk of the factorisation
     for _ in range(args.warmup):
         step.run()
-    ctx.set_profile(True)           # HIP-event pairs around the trailing-update launches; no host sync
+    # HIP-event pairs around the DOMINANT kernel's launches only (and the one predict-mean launch, whose pair count rides in
+    # slot 5): every recorded event is a marker between two kernels of its stream, 5 - 9 us each on a latency chain; the
+    # other stage timers run in an untimed pass below.  No host sync.
+    ctx.set_profile(True, slots=(slot, 5))
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -527,17 +532,19 @@ def main():
     if world > 1:
         elapsed = step.max_over_ranks(elapsed)
 
-    c5 = (not distributed) and args.workload.startswith('c5')
-    slot = 4 if c5 else 0      # the dominant kernel: NN update gemm of the variance solve (C5) / lower syrk of the factorisation
     # untimed extras: (a) the same kernel with the look-ahead off, i.e. without a panel factorisation running beside it,
     # (b) one pass with a HIP-event pair around every stage
     iso, stages = None, None
     if not distributed:
-        timed = [ctx.get_profile(i) for i in range(6)]
+        dom_ms, dom_launches = ctx.get_profile(slot)
         timed_flops = ctx.get_profile_flops(slot)
         timed_pairs = ctx.get_profile_flops(5)
         ctx.set_profile(False)
         check = step.check()       # the outputs of the last timed pass, before the untimed extras overwrite them
+        ctx.set_profile(True)      # (c) one pass like the timed ones with every stage timer on
+        step.run()
+        ctx.sync()
+        timed = [ctx.get_profile(i) for i in range(6)]
         ctx.set_lookahead(False)
         ctx.set_profile(True)
         step.run()
@@ -549,13 +556,10 @@ def main():
         iso = iso_flops / (iso_ms * 1e-3) / 1e12 if iso_ms > 0 else None
         stages = step.run_staged()
         (syrk_ms, syrk_launches), (panel_ms, _), (potrf_ms, _), (colupd_ms, colupd_launches) = timed[:4]
-        dom_ms, dom_launches = timed[slot]
+        stage_steps = 1            # the stage timers cover ONE (untimed) pass
     else:
-        syrk_ms, syrk_launches = ctx.get_profile(0)
-        panel_ms, _ = ctx.get_profile(1)
-        potrf_ms, _ = ctx.get_profile(2)
-        colupd_ms, colupd_launches = ctx.get_profile(3)
-        dom_ms, dom_launches = syrk_ms, syrk_launches
+        dom_ms, dom_launches = ctx.get_profile(0)
+        syrk_ms, panel_ms, potrf_ms, colupd_ms, stage_steps = dom_ms, 0.0, 0.0, 0.0, args.steps
         ctx.set_profile(False)
         check = step.check()
     ctx.set_profile(False)
@@ -592,9 +596,11 @@ def main():
                                  'family, other stream) share the GPU with this kernel; isolated_* = the same launches with the '
                                  'look-ahead off',
                          'isolated_achieved': iso, 'isolated_frac': (iso / PEAK_FP64_MFMA_TFLOPS) if iso else None},
-            'stages_ms_per_step': {'potrf': potrf_ms / args.steps, 'potrf_trailing_update': syrk_ms / args.steps,
-                                   'potrf_next_panel_column_update': colupd_ms / args.steps,
-                                   'potrf_panels_not_overlapped': panel_ms / args.steps},
+            'stages_ms_per_step': {'potrf': potrf_ms / stage_steps, 'potrf_trailing_update': syrk_ms / stage_steps,
+                                   'potrf_next_panel_column_update': colupd_ms / stage_steps,
+                                   'potrf_panels_not_overlapped': panel_ms / stage_steps,
+                                   'note': 'one untimed pass with every stage timer on; the timed region records events around the '
+                                           'dominant kernel only (roofline.launches / avg_launch_ms)'},
         }
         if stages is not None:
             out['stages_ms_one_pass'] = stages

@@ -315,6 +315,9 @@ int  mgpi_probe_hbm(mgpi_ctx* ctx, int64_t bytes, int iters, double* read_gbs, d
 int  mgpi_ctx_set_lookahead(mgpi_ctx* ctx, int on);
 /* per-kernel accumulated HIP-event time of the last mgpi_potrf_dev when profiling is enabled */
 int  mgpi_ctx_set_profile(mgpi_ctx* ctx, int on);
+/* the same for a subset of the slots below (bit s = slot s): every recorded event is a marker between two kernels of its
+ * stream; bench.py keeps only the dominant kernel's slot on inside its timed region (no reference counterpart: measurement) */
+int  mgpi_ctx_set_profile_slots(mgpi_ctx* ctx, unsigned mask);
 /* which: 0 = trailing update (lower syrk launches), 1 = panel (potf2+trsm+inner gemm; only when look-ahead is off),
  * 2 = whole potrf, 3 = look-ahead update of the next panel's block column, 4 = the big (main-stream) update launches of
  * the multi-rhs forward solve V = L^-1 K*^T of the variance path, 5 = the fused predict-mean kernel; ms and launches */

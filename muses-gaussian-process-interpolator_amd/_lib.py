@@ -133,6 +133,7 @@ _SIGNATURES = {
     'mgpi_probe_hbm': (ctypes.c_int, [_vp, c_int64, ctypes.c_int, c_double_p, c_double_p]),
     'mgpi_ctx_set_lookahead': (ctypes.c_int, [_vp, ctypes.c_int]),
     'mgpi_ctx_set_profile': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'mgpi_ctx_set_profile_slots': (ctypes.c_int, [_vp, ctypes.c_uint]),
     'mgpi_ctx_get_profile': (ctypes.c_int, [_vp, ctypes.c_int, c_double_p, ctypes.POINTER(c_int64)]),
     'mgpi_ctx_get_profile_flops': (ctypes.c_int, [_vp, ctypes.c_int, c_double_p]),
 }
@@ -327,8 +328,12 @@ class Context(object):
     def set_lookahead(self, on):
         check(self.lib.mgpi_ctx_set_lookahead(self.handle, int(bool(on))))
 
-    def set_profile(self, on):
-        check(self.lib.mgpi_ctx_set_profile(self.handle, int(bool(on))))
+    def set_profile(self, on, slots=None):
+        """HIP-event pairs around the library's launches; slots: an iterable of slot numbers to restrict them to"""
+        if on and slots is not None:
+            check(self.lib.mgpi_ctx_set_profile_slots(self.handle, sum(1 << int(s) for s in set(slots))))
+        else:
+            check(self.lib.mgpi_ctx_set_profile(self.handle, int(bool(on))))
 
     def get_profile(self, which):
         ms = ctypes.c_double(0.0)

@@ -244,10 +244,20 @@ extern "C" int mgpi_ctx_set_pivot_tol(mgpi_ctx* ctx, double tol) {
     return 0;
 }
 
+extern "C" int mgpi_ctx_set_profile(mgpi_ctx* ctx, int on);
+// which slots record HIP-event pairs (bit s = slot s); every recorded event is a marker between two kernels of its stream,
+// ~5 - 9 us each on a latency chain - bench.py keeps only the dominant kernel's slot on inside its timed region
+extern "C" int mgpi_ctx_set_profile_slots(mgpi_ctx* ctx, unsigned mask) {
+    MGPI_REQUIRE(ctx != nullptr, "mgpi_ctx_set_profile_slots: null ctx");
+    MGPI_TRY(mgpi_ctx_set_profile(ctx, 0));                     // drains the stream, clears the slots
+    ctx->profile = (int)(mask & ((1u << MGPI_PROF_SLOTS) - 1u));
+    return 0;
+}
+
 extern "C" int mgpi_ctx_set_profile(mgpi_ctx* ctx, int on) {
     MGPI_REQUIRE(ctx != nullptr, "mgpi_ctx_set_profile: null ctx");
     MGPI_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->profile = on;
+    ctx->profile = on ? (1 << MGPI_PROF_SLOTS) - 1 : 0;
     for (int s = 0; s < MGPI_PROF_SLOTS; ++s) {
         ctx->prof[s].used = 0;
         ctx->prof[s].ms = 0.0;
@@ -282,12 +292,12 @@ extern "C" int mgpi_ctx_get_profile_flops(mgpi_ctx* ctx, int which, double* flop
 }
 
 void mgpi_prof_flops(mgpi_ctx* ctx, int slot, double flops) {
-    if (ctx->profile) ctx->prof[slot].flops += flops;
+    if ((ctx->profile >> slot) & 1) ctx->prof[slot].flops += flops;
 }
 
 // HIP-event pair around a launch (or a group of launches) on the ctx stream; nothing waits on the host
 void mgpi_prof_begin(mgpi_ctx* ctx, int slot) {
-    if (!ctx->profile) return;
+    if (!((ctx->profile >> slot) & 1)) return;
     mgpi_prof_slot& p = ctx->prof[slot];
     if (p.used == p.begin.size()) {
         hipEvent_t a = nullptr, b = nullptr;
@@ -298,7 +308,7 @@ void mgpi_prof_begin(mgpi_ctx* ctx, int slot) {
     (void)hipEventRecord(p.begin[p.used], ctx->stream);
 }
 void mgpi_prof_end(mgpi_ctx* ctx, int slot) {
-    if (!ctx->profile) return;
+    if (!((ctx->profile >> slot) & 1)) return;
     mgpi_prof_slot& p = ctx->prof[slot];
     if (p.used >= p.end.size()) return;
     (void)hipEventRecord(p.end[p.used], ctx->stream);

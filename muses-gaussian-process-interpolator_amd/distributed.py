@@ -29,6 +29,7 @@ block step).  The solves use a replicated right-hand side: per block step one sm
 import ctypes
 import math
 import os
+import sys
 
 import numpy as np
 
@@ -696,6 +697,8 @@ class DistributedGP(object):
         # counter collection or serialising debug switches); MGPI_DIST_MERGED=0 keeps the two launches.
         merged = lookahead and os.environ.get('MGPI_DIST_MERGED', '1') != '0' and side is not be and be.overlaps(side)
         merged_min = int(os.environ.get('MGPI_DIST_MERGED_MIN', 12288))
+        if os.environ.get('MGPI_DIST_DEBUG'):
+            sys.stderr.write('factor: lookahead=%s merged=%s\n' % (lookahead, merged))
         target = 0
         if merged:
             be.count_reset()
