@@ -525,8 +525,14 @@ def main():
     ctx.set_profile(True, slots=(slot, 5))
     fence()
     t0 = time.perf_counter()
+    per_step = os.environ.get('MGPI_BENCH_PER_STEP') == '1'     # developer switch: a fence and a wall-clock stamp after every step (stderr)
     for _ in range(args.steps):
+        ts = time.perf_counter()
         step.run()
+        if per_step:
+            if os.environ.get('MGPI_BENCH_PER_STEP_FENCE', '1') != '0':
+                fence()
+            sys.stderr.write('step %.1f ms\n' % ((time.perf_counter() - ts) * 1e3))
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:

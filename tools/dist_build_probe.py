@@ -39,8 +39,12 @@ for rep in range(3):
     timed('variance', lambda: gp.variance(xs))
     be.sync()
     print('  step total %.1f ms' % ((time.perf_counter() - t0) * 1e3), flush=True)
-for rep in range(2):
+for prof in (False, True, False, True):
+    if prof:
+        ctx.set_profile(True, slots=(0, 5))
+    else:
+        ctx.set_profile(False)
     be.sync(); t0 = time.perf_counter()
     gp.build(); gp.factor(source_f=f); gp.solve(f); gp.mean(xs); gp.variance(xs)
     be.sync()
-    print('un-phased step %.1f ms' % ((time.perf_counter() - t0) * 1e3), flush=True)
+    print('un-phased step %.1f ms (event pairs around the trailing updates: %s)' % ((time.perf_counter() - t0) * 1e3, prof), flush=True)
