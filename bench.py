@@ -545,6 +545,7 @@ def main():
         dom_ms, dom_launches = ctx.get_profile(slot)
         timed_flops = ctx.get_profile_flops(slot)
         timed_pairs = ctx.get_profile_flops(5)
+        pred_ms, _ = ctx.get_profile(5)         # the fused predict-mean launches of the timed passes
         ctx.set_profile(False)
         check = step.check()       # the outputs of the last timed pass, before the untimed extras overwrite them
         ctx.set_profile(True)      # (c) one pass like the timed ones with every stage timer on
@@ -617,8 +618,13 @@ def main():
             else:       # riders: the variance solve's N^2 M flops run inside the factorisation's launches
                 out['stage_tflops_one_pass'] = {'potrf_and_variance_solve': (n**3 / 3.0 + float(n) * n * m) /
                                                 (stages['potrf_and_variance_solve'] * 1e-3) / 1e12}
-            out['predict_mean'] = {'pairs_per_s': timed_pairs / (timed[5][0] * 1e-3) if timed[5][0] > 0 else None,
-                                   'ms_per_step': timed[5][0] / args.steps}
+            out['predict_mean'] = {'pairs_per_s': timed_pairs / (pred_ms * 1e-3) if pred_ms > 0 else None,
+                                   'ms_per_step': pred_ms / args.steps}
+            # the backward sweep of the single-right-hand-side solve against the HBM roofline: the factor's lower triangle once
+            if stages.get('potrs'):
+                gbs = 8.0 * n * n / 2.0 / (stages['potrs'] * 1e-3) / 1e9
+                out['stage_hbm_one_pass'] = {'potrs_backward_sweep': {'GB/s': gbs, 'frac_of_8_TB/s': gbs / 8000.0,
+                                                                     'algorithmic_bytes': 8.0 * n * n / 2.0}}
         out['check'] = check
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(m=min(m, 4096))
