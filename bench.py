@@ -143,7 +143,7 @@ def syrk_launch_flops(n, nb=NB):
     return total
 
 
-def syrk_schedule_launches(n, nb=NB, panels=2, super_min=14336, merged_min=12288, tail_rows=2048):
+def syrk_schedule_launches(n, nb=NB, panels=2, super_min=14336, merged_min=8192, tail_rows=2048):
     """the trailing-update launches of the shipped two-level schedule (csrc/chol.hip, super_width) as (rows, contraction)
     pairs: the very first update is one panel wide, then `panels` panels per update while at least `super_min` rows would
     remain behind the super-panel.  While at least `merged_min` rows lie behind the NEXT super-panel the update is one

@@ -779,7 +779,9 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     // environment in which the two streams do not overlap (streams_overlap above: known switches + a device handshake).
     // An explicit MGPI_POTRF_MERGED=1 still forces the merged form (how the bounded wait's failure path is tested).
     static const int merged_env = getenv("MGPI_POTRF_MERGED") ? atoi(getenv("MGPI_POTRF_MERGED")) : -1;
-    static const int64_t merged_min = getenv("MGPI_MERGED_MIN") ? atoll(getenv("MGPI_MERGED_MIN")) : 12288;
+    // [r3] 12288 -> 8192 after the round's other changes (tools/sweep_r03_merged.sh, MGPI_MERGED_MIN = 4096 / 6144 / 8192 / 12288):
+    // C3 257.7 / 257.7 / 257.7 / 258.6 ms per step, potrf N = 20480 51.9 / 52.2 / 52.3 / 52.6 ms, N <= 10240 within noise
+    static const int64_t merged_min = getenv("MGPI_MERGED_MIN") ? atoll(getenv("MGPI_MERGED_MIN")) : 8192;
     // (the device is only asked when this matrix is large enough for a merged step to occur at all)
     const bool merged_on = merged_env >= 0 ? merged_env != 0 : (lookahead && pn > merged_min && streams_overlap(ctx) == 1);
     unsigned* d_sync = reinterpret_cast<unsigned*>(ctx->d_scal + 8064);
