@@ -1365,7 +1365,12 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
         };
         hipStream_t main_stream = ctx->stream;
         mgpi_stream_join_guard join_on_error{ctx, main_stream, true};
-        const bool lookahead = ctx->stream2 != nullptr && !ctx->no_lookahead;
+        // [r3] With the inverted diagonal blocks the solve of a (super-)block is a few gemms, no chain worth hiding: run side by
+        // side, the next block's solve and the big update slow each other down by more than the overlap saves (C3 variance
+        // 70.7 ms with the look-ahead, 69.0 without; N = 8192: 5.83 / 5.58 - tools/variance_lookahead_probe.py).  The look-ahead
+        // stays for the substitution form (MGPI_VAR_DINV=0); MGPI_TRSM_LOOKAHEAD=1 / 0 forces it on / off.
+        static const int trsm_la_env = getenv("MGPI_TRSM_LOOKAHEAD") ? atoi(getenv("MGPI_TRSM_LOOKAHEAD")) : -1;
+        const bool lookahead = ctx->stream2 != nullptr && !ctx->no_lookahead && (trsm_la_env >= 0 ? trsm_la_env != 0 : !inv);
         int64_t wc = super_width(0);
         MGPI_TRY(solve_super(0, wc, false));
         if (lookahead) MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));

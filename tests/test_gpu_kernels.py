@@ -348,7 +348,7 @@ def test_backward_sweep_by_inverted_blocks_against_substitution(ctx, n):
 
 @pytest.mark.parametrize('env', [{'MGPI_NO_LOOKAHEAD': '1'}, {'MGPI_POOL_MB': '0'},
                                  {'MGPI_SUPER_PANELS': '1', 'MGPI_SUPER_MIN': '512'}, {'MGPI_SUPER_PANELS': '2', 'MGPI_SUPER_MIN': '512'},
-                                 {'MGPI_VAR_DINV': '0'},
+                                 {'MGPI_VAR_DINV': '0'}, {'MGPI_TRSM_LOOKAHEAD': '1', 'MGPI_TRSM_SUPER_MIN': '512'},
                                  {'MGPI_TRSM_SUPER': '1', 'MGPI_TRSM_SUPER_MIN': '512'}, {'MGPI_TRSM_SUPER': '4', 'MGPI_TRSM_SUPER_MIN': '512'},
                                  {'MGPI_PANEL_STEP_ROWS': '0'}, {'MGPI_PANEL_STEP_ROWS': '0', 'MGPI_PANEL_PAIRS': '0'},
                                  {'MGPI_PANEL_STEP_ROWS': '1000000', 'MGPI_SUPER_MIN': '512'},
