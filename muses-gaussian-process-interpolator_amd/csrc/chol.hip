@@ -1406,11 +1406,12 @@ static int trsm_blocked(mgpi_ctx* ctx, const mgpi_mat* Lm, double* B, int64_t ld
                 }
                 MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
             } else {
-                MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, w1, nc, w, L + r1 * lda + r0, lda, X + r0 * ldb, ldb, B + r1 * ldb, ldb));
+                // one stream: ALL the rows below super-block k in one launch, then the next super-block's solve
+                mgpi_prof_begin(ctx, 4);
+                MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, t, nc, w, L + r1 * lda + r0, lda, X + r0 * ldb, ldb, B + r1 * ldb, ldb));
+                mgpi_prof_end(ctx, 4);
+                mgpi_prof_flops(ctx, 4, 2.0 * (double)t * (double)nc * (double)w);
                 MGPI_TRY(solve_super(r1, w1, false));
-                if (t2 > 0)
-                    MGPI_TRY(mgpi_launch_gemm(ctx, 0, 1, 0, t2, nc, w, L + (r1 + w1) * lda + r0, lda, X + r0 * ldb, ldb,
-                                              B + (r1 + w1) * ldb, ldb));
             }
             r0 = r1;
             wc = w1;
