@@ -335,6 +335,15 @@ class DistributedStep(object):
                 t = now
             sys.stderr.write('phases: ' + ', '.join(out) + '\n')
             return
+        if os.environ.get('MGPI_BENCH_HOST_STAMPS') == '1':  # developer switch: host time per call, NO extra syncs (stderr)
+            t = [time.perf_counter()]
+            gp.build(); t.append(time.perf_counter())
+            gp.factor(source_f=self.f); t.append(time.perf_counter())
+            gp.solve(self.f); t.append(time.perf_counter())
+            self.mean = gp.mean(self.xs); t.append(time.perf_counter())
+            self.var = gp.variance(self.xs); t.append(time.perf_counter())
+            sys.stderr.write('host: ' + ', '.join('%s %.1f' % (n, (b - a) * 1e3) for n, a, b in zip(('build', 'factor', 'solve', 'mean', 'variance'), t, t[1:])) + ' ms\n')
+            return
         gp.build()
         gp.factor(source_f=self.f)                  # the forward substitution rides along, block step by block step
         gp.solve(self.f)                            # ... so this is the backward sweep

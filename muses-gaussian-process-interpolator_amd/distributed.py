@@ -524,7 +524,7 @@ class DistributedGP(object):
                     be.copy(tmp, W(A, i0 * nb, mt, kc * nb, nb))
                 g.bcast_row(be, tmp, qk)
                 be.copy(wrow, tmp)
-            else:
+            elif not self._panels_in_place:
                 be.copy(wrow, W(A, i0 * nb, mt, kc * nb, nb))
         # 4. transposed role along process columns.  The blocks L[J][k] this rank needs (J = q mod Q, J > k) sit,
         #    after step 3, in the row panels of the ranks (J mod P, q) of its own process column.  For a source
@@ -543,8 +543,9 @@ class DistributedGP(object):
                 si, sj = lcm // g.P, lcm // g.Q                       # strides in local row / column blocks
                 jl0 = (J0 - g.q) // g.Q - j0
                 if g.P == 1 and not g.always:
-                    # the source is this rank: straight from the row panel into the column panel
-                    be.copy_blocks(wcol, jl0 * nb, sj * nb, wrow, ((J0 - pr) // g.P - i0) * nb, si * nb, nb, count)
+                    # the source is this rank: straight from the row panel into the column panel (on a 1 x 1 grid they are one)
+                    if wcol is not wrow:
+                        be.copy_blocks(wcol, jl0 * nb, sj * nb, wrow, ((J0 - pr) // g.P - i0) * nb, si * nb, nb, count)
                     continue
                 buf = W(bufs['gather'], 0, count * nb)
                 if g.p == pr:
@@ -565,7 +566,8 @@ class DistributedGP(object):
         k0, kl = blocks[0], blocks[-1]
         i00 = self._first_local(self.row_blocks, k0)
         j00 = self._first_local(self.col_blocks, k0)
-        off = self._slab_offset[si]
+        off, col0 = self._slab_offset[si], self._slab_col[si]
+        same = self._panels_in_place and g.P == 1          # 1 x 1: the column panel IS the row panel
         done = []
         for h, k in enumerate(blocks):
             i0 = self._first_local(self.row_blocks, k)
@@ -575,16 +577,17 @@ class DistributedGP(object):
                 jl = k // g.Q
                 for pan in done:
                     self._update(pan, jl, jl + 1, be)
-            wrow = W(self.row_panels, off + (i0 - i00) * nb, mt, h * nb, nb) if mt > 0 else None
-            wcol = W(bufs['wcol'], (j0 - j00) * nb, nt, h * nb, nb) if nt > 0 else None
+            wrow = W(self.row_panels, off + (i0 - i00) * nb, mt, col0 + h * nb, nb) if mt > 0 else None
+            wcol = (wrow if same else W(bufs['wcol'], (j0 - j00) * nb, nt, h * nb, nb)) if nt > 0 else None
             done.append(self._panel(k, be, bufs, wrow, wcol))
         # the slabs behind the LAST block of the super-panel, all of its columns
         i0 = self._first_local(self.row_blocks, kl)
         j0 = self._first_local(self.col_blocks, kl)
         mt, nt = self.mloc - i0 * nb, self.nloc - j0 * nb
         width = len(blocks) * nb
-        return dict(wrow=W(self.row_panels, off + (i0 - i00) * nb, mt, 0, width) if mt > 0 else None,
-                    wcol=W(bufs['wcol'], (j0 - j00) * nb, nt, 0, width) if nt > 0 else None,
+        wrow = W(self.row_panels, off + (i0 - i00) * nb, mt, col0, width) if mt > 0 else None
+        return dict(wrow=wrow,
+                    wcol=(wrow if same else W(bufs['wcol'], (j0 - j00) * nb, nt, 0, width)) if nt > 0 else None,
                     i0=i0, j0=j0, mt=mt, nt=nt, kblocks=len(blocks))
 
     def _update(self, pan, c_lo, c_hi, be, first_cols=0):
@@ -669,16 +672,24 @@ class DistributedGP(object):
         # persistent row panels: for every super-panel a slab with the blocks L[I][k] of the local block rows I > (its first
         # block), the panels of its block columns side by side (sum_k (N - k nb)/P x nb doubles = 8 N^2 / (2P) bytes: 8.6 GB per
         # rank at N = 65536 on 2 x 4).  The variance sweep reuses them, so L crosses xGMI once, not twice.
-        offs, total, views = [], 0, {}
+        # One process column (Q = 1): the block columns of a super-panel are adjacent LOCAL columns and L[I][k] of the local
+        # block rows is what the panel solve leaves in the local matrix - the "slab" of a super-panel is then a window of A
+        # itself (no copy per block step, no 8 N^2 / 2P bytes of slabs); on a 1 x 1 grid the column panels are the same window.
+        self._panels_in_place = g.Q == 1 and not g.always
+        offs, cols0, total, views = [], [], 0, {}
         for blocks in supers:
-            offs.append(total)
             i00 = self._first_local(self.row_blocks, blocks[0])
+            base, col0 = (i00 * nb, (blocks[0] // g.Q) * nb) if self._panels_in_place else (total, 0)
+            offs.append(base)
+            cols0.append(col0)
             for h, k in enumerate(blocks):
-                views[k] = (total + (self._first_local(self.row_blocks, k) - i00) * nb, h * nb)
+                views[k] = (base + (self._first_local(self.row_blocks, k) - i00) * nb, col0 + h * nb)
             total += self.mloc - i00 * nb
         total = max(total, nb)
-        self._slab_offset, self._row_panel_view = offs, views
-        if self.row_panels is None or self.row_panels.rows != total or self.row_panels.cols != wmax:
+        self._slab_offset, self._slab_col, self._row_panel_view = offs, cols0, views
+        if self._panels_in_place:
+            self.row_panels = self.A
+        elif self.row_panels is None or self.row_panels is self.A or self.row_panels.rows != total or self.row_panels.cols != wmax:
             self.row_panels = be.alloc(total, wmax, zero=False)
         self._fwd_y = self._fwd_acc = self._fwd_f = None
         if source_f is not None and os.environ.get('MGPI_DIST_FORWARD', '1') != '0':
@@ -939,7 +950,7 @@ class DistributedGP(object):
             if mt > 0:
                 i00 = self._first_local(self.row_blocks, blocks[0])
                 width = len(blocks) * nb
-                be.gemm_nn(W(V, i0 * nb, mt), W(self.row_panels, self._slab_offset[si] + (i0 - i00) * nb, mt, 0, width), W(vks, 0, width))
+                be.gemm_nn(W(V, i0 * nb, mt), W(self.row_panels, self._slab_offset[si] + (i0 - i00) * nb, mt, self._slab_col[si], width), W(vks, 0, width))
         sq_dev = be.alloc(per, 1)
         be.colsq(V, sq_dev)
         if g.P > 1 or g.always:
