@@ -76,9 +76,9 @@ static int launch_trsm_right_steps(hipStream_t stream, double* A, int64_t lda, i
 // `mode` splits the work for LARGE panels, where hundreds of workgroups repeating the 64 x 64 factorisation would take CU
 // time from the trailing update that runs beside the panel:
 //   mode 0  everything in one launch (every column-role workgroup factors the diagonal block itself)
-//   mode 1  one workgroup: update + factor the diagonal block, store it (strip S) and its LDS images (Lt, 1/diag) to F
-//   mode 2  the rest: column-role workgroups for the row blocks BELOW the diagonal block read the images from F
-//           instead of factoring, plus the update-role workgroups
+//   mode 1  one workgroup: update + factor the diagonal block, store it (strip S) and its LDS images (Lt, 1/diag) to F;
+//           the row blocks BELOW the diagonal block and the update-role tiles then run in panel_units_kernel, which reads
+//           the images from F instead of factoring ([r3]; the one-unit-per-workgroup form of that launch, "mode 2", is gone)
 #define PANEL_F_DOUBLES (IB * IB + IB)
 #ifdef PANEL_TRACE   // diagnostic build only (tools/contention_probe.py): per-workgroup phase stamps of the step kernels
 __device__ unsigned long long g_panel_trace[1 << 18];
@@ -120,11 +120,10 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t cp = c0 - IB, c1 = c0 + IB;
     panel_double4_t acc[4];
-    const int first_fused = (mode == 2) ? 1 : 0;                 // mode 2 has no workgroup for the diagonal block's rows
-    if ((int)blockIdx.x + first_fused >= nfused) {
+    if ((int)blockIdx.x >= nfused) {
         // update role: tile (ti, tj) of the rows >= c1, column blocks c1 + 64 tj (tj < rest_cols); only tiles on/below the diagonal
         int ti, tj;
-        panel_rest_decode((int)blockIdx.x + first_fused - nfused, nfused - 1, ti, tj);
+        panel_rest_decode((int)blockIdx.x - nfused, nfused - 1, ti, tj);
         double* C = A + (c1 + (int64_t)IB * ti) * lda + c1 + (int64_t)IB * tj;
         panel_load(acc, C, lda, w, g, c, false);
         panel_gemm_nt(acc, A + (c1 + (int64_t)IB * ti + 16 * w + c) * lda + cp + 2 * g, A + (c1 + (int64_t)IB * tj + c) * lda + cp + 2 * g, lda, 0, 4);
@@ -133,16 +132,13 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__
         PT_FLUSH(2);
         return;
     }
-    const int b = (int)blockIdx.x + first_fused;
+    const int b = (int)blockIdx.x;
     const int64_t r0 = c0 + (int64_t)IB * b;                      // this workgroup's rows
     if (b > 0) {
         panel_load(acc, A + r0 * lda + c0, lda, w, g, c, false);
         if (has_prev) panel_gemm_nt(acc, A + (r0 + 16 * w + c) * lda + cp + 2 * g, A + (c0 + c) * lda + cp + 2 * g, lda, 0, 4);
     }
-    if (mode == 2) {
-        for (int i = tid; i < IB * IB; i += 256) (&s.Lt[0][0])[i] = F[i];
-        if (tid < IB) s.invd[tid] = F[IB * IB + tid];
-    } else {
+    {
         if (tid < IB) s.dtol[tid] = ptol * fabs(diag0[tid]);
         // the diagonal block, current as of the previous step
         panel_double4_t accD[4];
@@ -250,16 +246,12 @@ static int launch_panel_step(mgpi_ctx* ctx, double* A, int64_t lda, int64_t c0, 
     } else {
         hipLaunchKernelGGL(panel_step_kernel, dim3(1), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused, rest_cols, pivot_base,
                            diag0, ctx->d_info, S, ctx->pivot_tol, 1, F, (int64_t)0, (int64_t)0, (int64_t)0);
-        // [r3] several units of work per workgroup (panel_units_kernel): the rows, then the update-role tiles; MGPI_PANEL_PAIRS=0 keeps mode 2
-        static const int units = getenv("MGPI_PANEL_PAIRS") ? atoi(getenv("MGPI_PANEL_PAIRS")) : 2;
-        if (units >= 2 && nfused - 1 >= 2) {
-            const int nrow = nfused - 1;
+        // [r3] the rows, then the update-role tiles, two units of work per workgroup (panel_units_kernel)
+        const int nrow = nfused - 1;
+        if (nrow > 0)
             hipLaunchKernelGGL(panel_units_kernel<2>, dim3((unsigned)((nrow + 1) / 2)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused, 1, F, 0);
-            if (nrest > 0)
-                hipLaunchKernelGGL(panel_units_kernel<2>, dim3((unsigned)((nrest + 1) / 2)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused, 0, F, (int)nrest);
-        } else if (nfused - 1 + nrest > 0)
-            hipLaunchKernelGGL(panel_step_kernel, dim3((unsigned)(nfused - 1 + nrest)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev,
-                               nfused, rest_cols, pivot_base, diag0, ctx->d_info, S, ctx->pivot_tol, 2, F, (int64_t)0, (int64_t)0, (int64_t)0);
+        if (nrest > 0)
+            hipLaunchKernelGGL(panel_units_kernel<2>, dim3((unsigned)((nrest + 1) / 2)), dim3(256), 0, ctx->stream, A, lda, c0, has_prev, nfused, 0, F, (int)nrest);
     }
     MGPI_HIP_TRY(hipGetLastError());
     return 0;
@@ -393,9 +385,8 @@ static int ensure_dinv(mgpi_ctx* ctx, const mgpi_mat* Lc) {
     double* X = Lm->dinv;
     const int64_t lda = Lm->ld;
     MGPI_HIP_TRY(hipMemsetAsync(X, 0, bytes, ctx->stream));
-    static const int halving_env = getenv("MGPI_DINV_HALVING") ? atoi(getenv("MGPI_DINV_HALVING")) : 1;
     const bool pow2 = nb >= IB && ((nb / IB) & (nb / IB - 1)) == 0;
-    if (halving_env != 0 && pow2 && nfull * (nb / IB) < 65536) {
+    if (pow2 && nfull * (nb / IB) < 65536) {
         double* T = nullptr;
         size_t tbytes = 0;
         MGPI_TRY(mgpi_pool_alloc(ctx, (size_t)nfull * (size_t)(nb / 2) * (size_t)(nb / 2) * sizeof(double) + 64, &T, &tbytes));
@@ -812,8 +803,7 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     // chain - needed (rocprofv3 timeline at N = 8192, profiles/r03_potrf_n8192_timeline.md: 250 us per column update beside
     // the big one, 82 us ahead of it).  potrf N = 8192 6.87 -> 6.6 ms, N = 12288 15.4 -> 14.9, loglikelihood N = 7933 7.05 -> 6.8.
     // Not with riders (their rows make the column update long enough to delay the big one; C2 12.15 -> 12.28 ms).
-    static const int col_first_env = getenv("MGPI_POTRF_COLFIRST") ? atoi(getenv("MGPI_POTRF_COLFIRST")) : 1;
-    const bool col_first = col_first_env != 0 && pm == 0;
+    const bool col_first = pm == 0;
     for (int64_t r0 = 0; r0 < pn && !tall;) {
         const int64_t w = wc;                                 // super-panel k (already factored)
         const int64_t t = pn - r0 - w;                        // trailing size
@@ -2026,9 +2016,8 @@ static int trsv_sweeps(mgpi_ctx* ctx, const mgpi_mat* Lm, double* v, int which) 
         const int w1 = (int)((pn - r1 < nb) ? (pn - r1) : nb);
         launch_trsv_update(ctx->stream, L, lda, v, r0, w, r1, pn - r1, 0, w1 > 0 ? L + r1 * lda + r1 : nullptr, w1);
     }
-    // [r3] backward: one fused launch per block (trsv_bwd_fused_kernel); MGPI_TRSV_FUSED=0 keeps the two launches per block
-    static const int fused_env = getenv("MGPI_TRSV_FUSED") ? atoi(getenv("MGPI_TRSV_FUSED")) : 1;
-    const bool fused = fused_env != 0 && nb <= TRSV_PIPE_MAXW && nb % IB == 0;
+    // [r3] backward: one fused launch per block (trsv_bwd_fused_kernel / trsv_bwd_dinv_kernel) for nb up to 1024
+    const bool fused = nb <= TRSV_PIPE_MAXW && nb % IB == 0;
     // MGPI_TRSV_DINV=1 (default): inverted diagonal blocks (trsv_bwd_dinv_kernel); 0: the substitution kernels
     // Only for factors whose diagonal spans at most MGPI_TRSV_DINV_RATIO (default 1e4, i.e. cond K up to ~1e8 by that
     // measure; the parity contract ends at 1e7): a product with an explicit inverse has a backward error of ~cond(L_bb) eps

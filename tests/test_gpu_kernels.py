@@ -350,7 +350,7 @@ def test_backward_sweep_by_inverted_blocks_against_substitution(ctx, n):
                                  {'MGPI_SUPER_PANELS': '1', 'MGPI_SUPER_MIN': '512'}, {'MGPI_SUPER_PANELS': '2', 'MGPI_SUPER_MIN': '512'},
                                  {'MGPI_VAR_DINV': '0'}, {'MGPI_TRSM_LOOKAHEAD': '1', 'MGPI_TRSM_SUPER_MIN': '512'},
                                  {'MGPI_TRSM_SUPER': '1', 'MGPI_TRSM_SUPER_MIN': '512'}, {'MGPI_TRSM_SUPER': '4', 'MGPI_TRSM_SUPER_MIN': '512'},
-                                 {'MGPI_PANEL_STEP_ROWS': '0'}, {'MGPI_PANEL_STEP_ROWS': '0', 'MGPI_PANEL_PAIRS': '0'},
+                                 {'MGPI_PANEL_STEP_ROWS': '0'},
                                  {'MGPI_PANEL_STEP_ROWS': '1000000', 'MGPI_SUPER_MIN': '512'},
                                  {'MGPI_POTRF_MERGED': '0'}, {'MGPI_TAIL_ROWS': '0'}, {'MGPI_TAIL_ROWS': '4096', 'MGPI_SUPER_MIN': '512'},
                                  {'MGPI_PANEL_INNER': '512'}, {'MGPI_PANEL_INNER': '128', 'MGPI_PANEL_INNER_ROWS': '0'},
@@ -360,19 +360,17 @@ def test_backward_sweep_by_inverted_blocks_against_substitution(ctx, n):
                                  {'AMD_SERIALIZE_KERNEL': '3', 'MGPI_MERGED_MIN': '0', 'MGPI_SUPER_MIN': '512'},
                                  {'HIP_LAUNCH_BLOCKING': '1', 'MGPI_MERGED_MIN': '0', 'MGPI_SUPER_MIN': '512'},
                                  {'GPU_MAX_HW_QUEUES': '1', 'MGPI_MERGED_MIN': '0', 'MGPI_SUPER_MIN': '512'},
-                                 {'MGPI_LL_CHUNK_BYTES': '12000000'}, {'MGPI_TRSV_DINV': '0'}, {'MGPI_TRSV_DINV': '0', 'MGPI_TRSV_FUSED': '0'},
-                                 {'MGPI_DINV_HALVING': '0'}, {}],
+                                 {'MGPI_LL_CHUNK_BYTES': '12000000'}, {'MGPI_TRSV_DINV': '0'}, {}],
                          ids=lambda e: ','.join('%s=%s' % kv for kv in e.items()) or 'defaults')
 def test_developer_switch_variants(env):
     """the schedule thresholds and the few alternative forms that ship behind an environment switch (DESIGN.md section c)
     compute the same results: no look-ahead, no buffer pool, 1 / 2 panels per trailing update (with a threshold small enough
-    for the two-level schedule to engage), the panel step as one launch everywhere / split everywhere (rows two blocks per workgroup, or one), the separate
+    for the two-level schedule to engage), the panel step as one launch everywhere / split everywhere, the separate
     column update instead of the merged trailing update, tail and sub-panel thresholds, the general kernel-term loop, the
     MFMA form of predict-mean, 128-wide tiles for skinny updates; environments that serialise kernels (AMD_SERIALIZE_KERNEL,
     HIP_LAUNCH_BLOCKING, one hardware queue) with a threshold that WOULD engage the merged trailing update - the library must
     notice and take the separate column update instead of stalling in its bounded wait; a log-likelihood batch split into
-    chunks; the backward sweep of the solve by substitution (fused launch / two launches per block) instead of inverted diagonal
-    blocks, and those inverses by the round-2 block substitution instead of recursive halving.  (The measured losers of rounds 1-2 - ping-pong and
+    chunks; the backward sweep of the solve by substitution instead of inverted diagonal blocks.  (The measured losers of rounds 1-2 - ping-pong and
     register-staged gemm, round-1 panel kernels, left-looking steps, matrix-pipe factorisation - are gone, round 3.)"""
     import os
     import subprocess
