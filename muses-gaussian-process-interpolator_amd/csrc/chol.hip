@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void panel_step_kernel(double* __restrict__
     PT_FLUSH(1);
 }
 
-// [r3] The rows launch of a SPLIT step (mode 2 of panel_step_kernel) with NU units of work per workgroup, as a kernel of its
+// [r3] The rows launch of a SPLIT step (what follows a mode-1 launch of panel_step_kernel) with NU units of work per workgroup, as a kernel of its
 // own (panel_step_kernel keeps its register budget): rows != 0: row blocks 1 + NU p .. NU + NU p below the diagonal block, their
 // substitution chains interleaved (trsm_acc_mxn), the factor's images from F; rows == 0: update-role tiles NU p .. NU p + NU - 1
 // (ntiles in all).  A unit index beyond the last one is clamped to it: the same loads, the same arithmetic, the same values
@@ -1996,13 +1996,15 @@ static void launch_trsv_update(hipStream_t stream, const double* L, int64_t lda,
     }
 }
 
-// L y = f, then L^T x = y, one right-hand side.  Per outer block: a one-workgroup substitution kernel on the diagonal
+// L y = f, then L^T x = y, one right-hand side.  FORWARD, per outer block: a one-workgroup substitution kernel on the diagonal
 // block (the chain) and a wide gemv on everything that block feeds (HBM-bound), all on one stream.  Splitting the gemv
 // so that only the next block's entries stay on the chain and the rest runs on the second stream was measured and
-// dropped: the event record/wait pairs it puts on the chain cost more than the ~15 us gemv they take off it
-// (11.4 vs 10.3 ms at N = 32768, 2.55 vs 2.15 ms at N = 8192).
-// fwd_only: stop after L y = f (what the quadratic form f^T K^-1 f = y^T y of the log-likelihood needs)
-// which: 1 = forward only (L y = f), 2 = backward only (L^T x = y), 3 = both
+// dropped in round 2: the event record/wait pairs it puts on the chain cost more than the ~15 us gemv they take off it
+// (11.4 vs 10.3 ms at N = 32768, 2.55 vs 2.15 ms at N = 8192).  BACKWARD [r3]: one launch per block that holds the block's
+// solve AND the gemv of the previous block's solution (trsv_bwd_dinv_kernel / trsv_bwd_fused_kernel above) - what the
+// two-stream split wanted, without events.
+// which: 1 = forward only (L y = f: what the quadratic form f^T K^-1 f = y^T y of the log-likelihood needs),
+//        2 = backward only (L^T x = y), 3 = both
 static int trsv_sweeps(mgpi_ctx* ctx, const mgpi_mat* Lm, double* v, int which) {
     const int64_t pn = Lm->prows <= Lm->pcols ? Lm->prows : mgpi_roundup(Lm->rows, IB);
     const int64_t lda = Lm->ld;
