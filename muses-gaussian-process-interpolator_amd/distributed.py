@@ -707,7 +707,7 @@ class DistributedGP(object):
         # launches side by side.  Only where the two contexts' kernels do overlap (bounded device handshake; not under
         # counter collection or serialising debug switches); MGPI_DIST_MERGED=0 keeps the two launches.
         merged = lookahead and os.environ.get('MGPI_DIST_MERGED', '1') != '0' and side is not be and be.overlaps(side)
-        merged_min = int(os.environ.get('MGPI_DIST_MERGED_MIN', 12288))
+        merged_min = int(os.environ.get('MGPI_DIST_MERGED_MIN', 8192))
         if os.environ.get('MGPI_DIST_DEBUG'):
             sys.stderr.write('factor: lookahead=%s merged=%s\n' % (lookahead, merged))
         target = 0
