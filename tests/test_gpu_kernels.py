@@ -309,6 +309,29 @@ def test_trtri_neg_strided_batch(ctx, w, batch, row_step, col_step):
         _lib.check(ctx.lib.mgpi_trtri_neg_dev(ctx.handle, dA.handle, r0, c0, row_step, col_step, w, batch + 50, out.handle))
 
 
+@pytest.mark.parametrize('nb', [128, 384, 640, 1024, 2048])
+def test_other_outer_block_sizes(nb):
+    """contexts with another outer block than the 512 every measurement uses: nb = 384 / 640 are not 64 * 2^p (the diagonal-block
+    inverses fall back to the block-substitution routine), 1024 is the widest block of the fused backward sweep, 2048 takes the
+    two-launch sweep.  alpha against numpy's solve, the residual, and the variance against the default context's [r3]"""
+    rng = np.random.default_rng(5)
+    n = 3000
+    x = rng.random((n, 3))
+    f = np.sin(3 * x[:, 0]) + x[:, 1]
+    k, nug = mgpi.SquaredExponentialKernel(1.0, 0.2, 0.2, 0.2), mgpi.WhiteNoiseKernel(1e-2)
+    K = mgpi.Interpolator._x2cov(x, x, k + nug)
+    ref = np.linalg.solve(K, f)
+    q = x[:200] + 0.01
+    mean0, var0 = mgpi.Interpolator(k, nugget=nug).condition_diag(q, x, f)
+    it = mgpi.Interpolator(k, nugget=nug, context=mgpi.Context(nb=nb))
+    a = it.compress(x, f)
+    assert np.max(np.abs(a - ref)) < 1e-9 * np.max(np.abs(ref))
+    assert np.max(np.abs(K @ a - f)) < 1e-12 * max(1.0, np.max(np.abs(f)))
+    mean, var = it.condition_diag(q, x, f)
+    assert np.max(np.abs(mean - mean0)) < 1e-11 * np.max(np.abs(mean0))
+    assert np.max(np.abs(var - var0)) < 1e-11
+
+
 @pytest.mark.parametrize('n', [700, 5000, 9000])
 def test_backward_sweep_by_inverted_blocks_against_substitution(ctx, n):
     """[r3] the backward sweep of a single-right-hand-side solve takes the inverted diagonal blocks (trsv_bwd_dinv_kernel) when the
