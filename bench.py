@@ -635,6 +635,14 @@ def main():
                 out['stage_hbm_one_pass'] = {'potrs_backward_sweep': {'GB/s': gbs, 'frac_of_8_TB/s': gbs / 8000.0,
                                                                      'algorithmic_bytes': 8.0 * n * n / 2.0}}
         out['check'] = check
+        if world == 1:
+            # what THIS box's GPU sustains on the fp64 matrix pipe right now (the boxes of one pool differ by a few per cent);
+            # the roofline above stays on the 78.6 TFLOP/s spec peak
+            try:
+                out['device_probe'] = {'mfma_f64_tflops': ctx.probe_mfma_f64(),
+                                       'what': 'back-to-back v_mfma_f64_16x16x4, random operands, 2 x 4 waves per CU, ~0.1 s, after the timed region'}
+            except Exception as err:      # a diagnostic, never a reason to lose the line
+                out['device_probe'] = {'error': str(err)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(m=min(m, 4096))
         print(json.dumps(out), flush=True)

@@ -325,6 +325,12 @@ class Context(object):
         """pivot k must exceed tol * K_kk; default 100 eps, 0 = LAPACK's pivot > 0 (include/mgpi_hip.h)"""
         check(self.lib.mgpi_ctx_set_pivot_tol(self.handle, float(tol)))
 
+    def probe_mfma_f64(self, iters=200000):
+        """TFLOP/s of back-to-back v_mfma_f64_16x16x4 (random operands, two 4-wave workgroups per CU): what this GPU sustains"""
+        out = ctypes.c_double(0.0)
+        check(self.lib.mgpi_probe_mfma_f64(self.handle, int(iters), ctypes.byref(out)))
+        return float(out.value)
+
     def set_lookahead(self, on):
         check(self.lib.mgpi_ctx_set_lookahead(self.handle, int(bool(on))))
 
