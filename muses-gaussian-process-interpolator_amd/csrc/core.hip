@@ -107,6 +107,8 @@ static int pool_alloc(mgpi_ctx* ctx, size_t bytes, double** out, size_t* got) {
         pool->blocks.erase(pool->blocks.begin() + best);
         return 0;
     }
+    static const bool pool_debug = getenv("MGPI_POOL_DEBUG") && atoi(getenv("MGPI_POOL_DEBUG")) != 0;
+    if (pool_debug) fprintf(stderr, "mgpi pool: miss, hipMalloc of %.1f MB (%zu blocks pooled, %.1f MB)\n", bytes / 1048576.0, pool->blocks.size(), pool->held / 1048576.0);
     hipError_t e = hipMalloc((void**)out, bytes);
     if (e != hipSuccess && !pool->blocks.empty()) {          // give the pooled memory back and try once more
         (void)hipGetLastError();

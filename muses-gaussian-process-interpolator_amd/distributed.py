@@ -226,6 +226,7 @@ class HipTileBackend(object):
         self.ctx = ctx if ctx is not None else _lib.default_context()
         self.lib = self.ctx.lib
         self._side = None
+        self._overlap_verdict = {}
 
     # -- second stream for the look-ahead panel (its own mgpi ctx = its own HIP stream and workspace) -----------
     def side_backend(self):
@@ -340,9 +341,12 @@ class HipTileBackend(object):
 
     def overlaps(self, other):
         """do kernels of this backend's stream and of `other`'s run side by side (bounded device handshake)?"""
-        yes = ctypes.c_int(0)
-        _lib.check(self.lib.mgpi_ctx_streams_overlap(self.ctx.handle, other.ctx.handle, ctypes.byref(yes)))
-        return bool(yes.value)
+        cached = self._overlap_verdict.get(id(other))
+        if cached is None:                       # asked once per pair of contexts: the answer is a property of the process
+            yes = ctypes.c_int(0)
+            _lib.check(self.lib.mgpi_ctx_streams_overlap(self.ctx.handle, other.ctx.handle, ctypes.byref(yes)))
+            cached = self._overlap_verdict[id(other)] = bool(yes.value)
+        return cached
 
     def gemm_nn(self, c, a, b):
         _lib.check(self.lib.mgpi_gemm_nn_dev(self.ctx.handle, a.handle, b.handle, c.handle))
@@ -666,8 +670,13 @@ class DistributedGP(object):
         supers = self.super_panels_ = self.super_panels()
         wmax = max(len(b) for b in supers) * nb
         # panel buffers: two sets (parity of the super-panel), allocated once
-        bufs = [dict(lkk=be.alloc(nb, nb, zero=False), wcol=be.alloc(max(self.nloc, nb), wmax, zero=False),
-                     gather=be.alloc(max(self.nloc, nb), nb, zero=False), rowtmp=be.alloc(max(self.mloc, nb), nb, zero=False))
+        # (on grids that never use one of them - no column panels of their own on 1 x 1, nothing to gather with one process row,
+        # nothing to stage with one process column - it is not allocated)
+        one_row, one_col = g.P == 1 and not g.always, g.Q == 1 and not g.always
+        bufs = [dict(lkk=be.alloc(nb, nb, zero=False),
+                     wcol=None if (one_row and one_col) else be.alloc(max(self.nloc, nb), wmax, zero=False),
+                     gather=None if one_row else be.alloc(max(self.nloc, nb), nb, zero=False),
+                     rowtmp=None if one_col else be.alloc(max(self.mloc, nb), nb, zero=False))
                 for _ in range(2)]
         # persistent row panels: for every super-panel a slab with the blocks L[I][k] of the local block rows I > (its first
         # block), the panels of its block columns side by side (sum_k (N - k nb)/P x nb doubles = 8 N^2 / (2P) bytes: 8.6 GB per
