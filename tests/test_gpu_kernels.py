@@ -282,6 +282,12 @@ def test_profile_counts_the_flops_of_the_schedule(ctx):
     ctx.set_profile(False)
     assert flops == bench.syrk_schedule_flops(n) and flops != bench.syrk_launch_flops(n)
     assert launches > 0 and ms > 0
+    # a subset of the slots (what bench.py keeps on inside its timed region): the others record nothing
+    ctx.set_profile(True, slots=(0,))
+    it.fit(x)
+    assert ctx.get_profile_flops(0) == flops and ctx.get_profile(0)[1] == launches
+    assert ctx.get_profile(2) == (0.0, 0) and ctx.get_profile(1) == (0.0, 0)
+    ctx.set_profile(False)
 
 
 @pytest.mark.parametrize('w,batch,row_step,col_step', [(64, 1, 0, 0), (128, 3, 256, 128), (512, 2, 512, 1024), (256, 5, 256, 256)])
