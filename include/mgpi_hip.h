@@ -140,7 +140,7 @@ int  mgpi_potrf_dev(mgpi_ctx* ctx, mgpi_mat* K, double* logdet);
  * One right-hand side: block substitution with the factor's nb x nb diagonal blocks; for the BACKWARD sweep the diagonal-block
  * solves are products with the inverted blocks (built once per factor, cached on the handle, shared with mgpi_predict_var_dev)
  * when the factor's diagonal spans at most 1e4 (MGPI_TRSV_DINV_RATIO) as the status read-back of mgpi_potrf_dev /
- * mgpi_posv_dev saw it - i.e. cond K up to ~1e8 by that measure - and plain substitutions otherwise (ill-conditioned factors,
+ * mgpi_posv_dev saw it - cond K up to ~4e10 for squared-exponential + nugget matrices, profiles/r03_dinv_accuracy.md - and plain substitutions otherwise (ill-conditioned factors,
  * handles whose status this library never read, MGPI_TRSV_DINV=0).  The two forms agree to ~cond(L_bb) eps. */
 int  mgpi_potrs_dev(mgpi_ctx* ctx, const mgpi_mat* L, mgpi_mat* B);
 /* factor AND solve (LAPACK's dposv):  K <- L,  B <- K^-1 B,  *logdet as above.  The reference's

@@ -2021,8 +2021,8 @@ static int trsv_sweeps(mgpi_ctx* ctx, const mgpi_mat* Lm, double* v, int which) 
     // [r3] backward: one fused launch per block (trsv_bwd_fused_kernel / trsv_bwd_dinv_kernel) for nb up to 1024
     const bool fused = nb <= TRSV_PIPE_MAXW && nb % IB == 0;
     // MGPI_TRSV_DINV=1 (default): inverted diagonal blocks (trsv_bwd_dinv_kernel); 0: the substitution kernels
-    // Only for factors whose diagonal spans at most MGPI_TRSV_DINV_RATIO (default 1e4, i.e. cond K up to ~1e8 by that
-    // measure; the parity contract ends at 1e7): a product with an explicit inverse has a backward error of ~cond(L_bb) eps
+    // Only for factors whose diagonal spans at most MGPI_TRSV_DINV_RATIO (default 1e4: cond K up to ~4e10 for the SE + nugget
+    // family, profiles/r03_dinv_accuracy.md; the parity contract ends at 1e7): a product with an explicit inverse has a backward error of ~cond(L_bb) eps
     // instead of eps, and at cond K ~ 5e15 (tests/test_gpu_configs.py::test_pivot_tolerance_is_configurable) that showed:
     // 6e-13 against < 1e-13.  A factor whose status was never read (range unknown) takes the substitution.
     static const int dinv_env = getenv("MGPI_TRSV_DINV") ? atoi(getenv("MGPI_TRSV_DINV")) : 1;
