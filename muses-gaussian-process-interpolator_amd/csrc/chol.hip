@@ -665,15 +665,17 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     const int64_t step_rows = step_rows_env >= 0 ? step_rows_env : (small_matrix ? INT64_MAX / 2 : 8192);
     ctx->skinny_tiles = small_matrix ? 1300 : 448;
     int64_t strip_first = pn / IB;                      // first 64-block whose factored diagonal block waits in the scratch strip
-    auto factor_panel = [&](int64_t r0, int64_t w) -> int {
+    // the steps of the columns [c_begin, c_end) of the panel [r0, r0 + w)
+    auto factor_panel_range = [&](int64_t r0, int64_t w, int64_t c_begin, int64_t c_end) -> int {
         const bool split = prow - r0 - IB > step_rows;
-        for (int64_t c0 = r0; c0 < r0 + w; c0 += IB) {
+        for (int64_t c0 = c_begin; c0 < c_end; c0 += IB) {
             MGPI_TRY(launch_panel_step(ctx, A, lda, c0, c0 > r0 ? 1 : 0, prow - c0 - IB, r0 + w, pivot_base + c0, ctx->d_diag + c0,
                                        ctx->d_diag + ctx->diag_len + c0 * IB, split));
             if (c0 / IB < strip_first) strip_first = c0 / IB;
         }
         return 0;
     };
+    auto factor_panel = [&](int64_t r0, int64_t w) -> int { return factor_panel_range(r0, w, r0, r0 + w); };
 
     // Two-level blocking.  The panels are nb wide (the blocked algorithm of the reference configuration), but while
     // the trailing matrix is large the trailing update is applied once per SUPER-PANEL of MGPI_SUPER_PANELS (default
@@ -792,10 +794,25 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
     if (pn <= tail_rows) wc = pn;                                // small matrices: one panel from the start
     if (tall) wc = ncols;                                        // a block column: its columns are one super-panel, and that is all
     mgpi_prof_begin(ctx, 1);
-    if (!tall && wc == pn && pn <= tail_rows) MGPI_TRY(factor_panel(0, pn));
-    else MGPI_TRY(factor_super(0, wc, false));
-    mgpi_prof_end(ctx, 1);
-    MGPI_TRY(forward_columns(0, wc));
+    // [r3] a panel wider than nb (the whole of a small matrix, the tail of a large one) with a forward sweep riding along:
+    // nb columns at a time, so that the sweep of each block starts when ITS steps are done, not after the panel's last one
+    auto factor_wide_panel = [&](int64_t r0, int64_t w) -> int {
+        if (fwd_rhs == nullptr) return factor_panel(r0, w);
+        for (int64_t c = r0; c < r0 + w; c += nb) {
+            const int64_t ce = (c + nb < r0 + w) ? c + nb : r0 + w;
+            MGPI_TRY(factor_panel_range(r0, w, c, ce));
+            MGPI_TRY(forward_columns(c, ce));
+        }
+        return 0;
+    };
+    if (!tall && wc == pn && pn <= tail_rows) {
+        MGPI_TRY(factor_wide_panel(0, pn));
+        mgpi_prof_end(ctx, 1);
+    } else {
+        MGPI_TRY(factor_super(0, wc, false));
+        mgpi_prof_end(ctx, 1);
+        MGPI_TRY(forward_columns(0, wc));
+    }
     if (lookahead) MGPI_HIP_TRY(hipEventRecord(ctx->ev_upd, main_stream));
     bool panel_on_side = false;                                  // is the current super-panel the product of stream2?
     // [r3] In the un-merged look-ahead steps the main stream's update of the rest waits until the next panel's block column
@@ -820,9 +837,8 @@ static int potrf_enqueue(mgpi_ctx* ctx, mgpi_mat* K, int64_t pivot_base, int kee
             mgpi_prof_flops(ctx, 0, (double)t * ((double)t + 1.0) * (double)w);
             MGPI_TRY(rider_update(r0, w, r1, pn));
             mgpi_prof_begin(ctx, 1);
-            MGPI_TRY(factor_panel(r1, t));
+            MGPI_TRY(factor_wide_panel(r1, t));
             mgpi_prof_end(ctx, 1);
-            MGPI_TRY(forward_columns(r1, r1 + t));
             break;
         }
         const int64_t w1 = super_width(r1);                  // super-panel k+1
